@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by importing the REAL reference (runs only in the build container).
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tools/gen_golden.py
+
+The reference at /root/reference is put first on sys.path, so ``nicediffusion`` below is the reference's own
+package (the product package lives under ``nice-diffusion_amd/`` and is NOT on the path here).  Nothing from
+the reference is copied: only inputs (seeds, small tensors) and the outputs it computed are written.
+
+Fixture design follows SURVEY.md 8(c): synthetic weights from numpy's default_rng in state_dict order with the
+zero-initialised tensors overwritten, stored x_T and per-step noise, per-layer intermediates, teacher-forced
+per-step vectors plus free-running loops on contractive weights.
+"""
+import json
+import os
+import sys
+
+REF = '/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('MPLBACKEND', 'Agg')
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nicediffusion.model import DiffusionModel  # noqa: E402  (reference)
+from nicediffusion.diffusion import Diffusion  # noqa: E402  (reference)
+from nicediffusion import default_args as ref_presets  # noqa: E402
+from nicediffusion.utils import make_argparser, get_dicts_from_args  # noqa: E402
+
+from oracle import unet_oracle as UO  # noqa: E402
+from oracle import diffusion_oracle as DO  # noqa: E402
+from tests.cases import TINY_CFGS, SCHEDULE_CASES, SAMPLER_CASES, CLI_CASES, labels_for  # noqa: E402
+
+assert DiffusionModel.__module__ == 'nicediffusion.model' and \
+    sys.modules['nicediffusion'].__path__[0].startswith(REF), 'reference not first on path'
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def ref_model(cfg, sd):
+    m = DiffusionModel(**cfg)
+    m.load_state_dict(sd, strict=True)        # also pins oracle.param_shapes key names
+    return m.eval()
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: np.asarray(v) for k, v in arrs.items()})
+    print('wrote', name, len(arrs), 'arrays')
+
+
+# ------------------------------------------------------------------------------------------------ schedules (A1)
+def gen_schedules():
+    out = {}
+    for name, (T, S, sched) in SCHEDULE_CASES.items():
+        torch.manual_seed(0)
+        m = DiffusionModel(resolution=8, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                           attention_resolutions=(), channel_mult=(1,))
+        d = Diffusion(m, T, S, 'small', 'simple', beta_schedule=sched, device=torch.device('cpu'))
+        for attr in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod',
+                     'sqrt_one_minus_alphas_cumprod', 'sqrt_reciprocal_alphas_cumprod',
+                     'sqrt_reciprocal_alphas_minus_one_cumprod', 'posterior_mean_coef_x0', 'posterior_mean_coef_xt',
+                     'posterior_variance', 'log_posterior_var_clipped'):
+            out['{}/{}'.format(name, attr)] = getattr(d, attr)
+        out['{}/timestep_map'.format(name)] = d.timestep_map.numpy()
+    save('schedules.npz', **out)
+
+
+# ------------------------------------------------------------------------------------------------ tiny forwards
+def gen_tiny_forwards():
+    for name, cfg in TINY_CFGS.items():
+        sd = UO.synth_state_dict(cfg, seed=1234)
+        m = ref_model(cfg, sd)
+        B = 3
+        g = np.random.default_rng(7)
+        R = cfg['resolution']
+        x = torch.from_numpy(g.standard_normal((B, cfg['in_channels'], R, R)).astype(np.float32))
+        t = torch.tensor([2, 501, 998][:B], dtype=torch.long)
+        y = labels_for(cfg, B)
+        taps = {}
+        hooks = []
+
+        def mk(nm):
+            def hook(mod, inp, outp):
+                taps[nm] = outp.detach().clone()
+            return hook
+        for nm, mod in m.named_modules():
+            # blocks only (downsampling.i.j / middle_block.j / upsampling.i.j) -> one golden per HIP op group
+            parts = nm.split('.')
+            if (parts[0] in ('downsampling', 'upsampling') and len(parts) == 3) or \
+                    (parts[0] == 'middle_block' and len(parts) == 2):
+                hooks.append(mod.register_forward_hook(mk(nm)))
+        with torch.no_grad():
+            out = m(x, t, y) if y is not None else m(x, t)
+        for h in hooks:
+            h.remove()
+        # oracle agreement is asserted at generation time too
+        o_taps = {}
+        o = UO.unet_forward(sd, cfg, x, t, y, taps=o_taps)
+        err = (o - out).abs().max().item()
+        assert err < 2e-5, (name, err)
+        arrs = dict(x=x.numpy(), t=t.numpy(), out=out.numpy())
+        if y is not None:
+            arrs['y'] = y.numpy()
+        for k, v in taps.items():
+            assert (o_taps[k] - v).abs().max().item() < 2e-5, (name, k)
+            arrs['tap/' + k] = v.numpy()
+        save('fwd_{}.npz'.format(name), **arrs)
+        print('  ', name, 'oracle-vs-reference max err', err, 'out absmax', out.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ presets
+def gen_presets():
+    meta = {}
+    for pname, margs in (('EMNIST', ref_presets.EMNIST_MODEL_ARGS), ('OPENAI_64', ref_presets.OPENAI_64_MODEL_ARGS),
+                         ('OPENAI_128', ref_presets.OPENAI_128_MODEL_ARGS),
+                         ('OPENAI_256', ref_presets.OPENAI_256_MODEL_ARGS)):
+        m = DiffusionModel(**margs)
+        sdref = m.state_dict()
+        shapes = UO.param_shapes(dict(margs))
+        assert list(shapes.keys()) == list(sdref.keys()), pname
+        assert all(tuple(sdref[k].shape) == tuple(v) for k, v in shapes.items()), pname
+        meta[pname] = dict(n_tensors=len(sdref), n_params=int(sum(v.numel() for v in sdref.values())),
+                           keys=list(sdref.keys()), shapes=[list(v.shape) for v in sdref.values()])
+        del m
+    with open(os.path.join(OUT, 'preset_state_dicts.json'), 'w') as f:
+        json.dump(meta, f)
+    print('wrote preset_state_dicts.json', {k: (v['n_tensors'], v['n_params']) for k, v in meta.items()})
+
+    # EMNIST preset forward, B=2 (SURVEY 8(d) synthetic weights)
+    cfg = dict(ref_presets.EMNIST_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    torch.manual_seed(0)
+    x = torch.randn(2, 1, 28, 28)
+    t = torch.tensor([10, 990])
+    y = torch.tensor([3, 26])
+    with torch.no_grad():
+        out = m(x, t, y)
+    o = UO.unet_forward(sd, cfg, x, t, y)
+    assert (o - out).abs().max().item() < 2e-5
+    save('fwd_preset_emnist.npz', x=x.numpy(), t=t.numpy(), y=y.numpy(), out=out.numpy())
+
+    # 64x64 preset forward, B=1
+    cfg = dict(ref_presets.OPENAI_64_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 64, 64)
+    t = torch.tensor([498])
+    y = torch.tensor([37])
+    with torch.no_grad():
+        out = m(x, t, y)
+    o = UO.unet_forward(sd, cfg, x, t, y)
+    err = (o - out).abs().max().item()
+    print('   64x64 preset oracle-vs-reference', err, 'absmax', out.abs().max().item())
+    assert err < 5e-5
+    save('fwd_preset_64.npz', x=x.numpy(), t=t.numpy(), y=y.numpy(), out=out.numpy())
+
+
+# ------------------------------------------------------------------------------------------------ init parity
+def gen_init():
+    cfg = TINY_CFGS['adagn_updown']
+    torch.manual_seed(0)
+    m = DiffusionModel(**cfg)
+    sd = m.state_dict()
+    keys = ['step_embed.0.weight', 'downsampling.0.0.weight', 'downsampling.1.0.in_conv.weight',
+            'downsampling.1.0.out_conv.weight', 'middle_block.1.qkv_nin.weight', 'middle_block.1.proj_out.weight',
+            'class_embedding.weight', 'out.2.weight', 'upsampling.0.0.step_embedding.bias']
+    save('init_seed0.npz', **{k: sd[k].numpy() for k in keys})
+
+
+# ------------------------------------------------------------------------------------------------ samplers
+def gen_samplers():
+    for name, case in SAMPLER_CASES.items():
+        cfg = dict(TINY_CFGS[case['cfg']])
+        learned = case['var'] in ('learned', 'learned_interpolation')
+        cfg['out_channels'] = cfg['in_channels'] * (2 if learned else 1)
+        sd = UO.synth_state_dict(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+        m = ref_model(cfg, sd)
+        S = case['S']
+        d = Diffusion(m, 1000, S, case['var'], 'simple', beta_schedule=case['sched'],
+                      guidance_method=case.get('guidance'), guidance_strength=case.get('w'),
+                      use_ddim=case['ddim'], ddim_eta=case.get('eta'), device=torch.device('cpu'))
+        B = 2
+        R = cfg['resolution']
+        C = cfg['in_channels']
+        torch.manual_seed(0)
+        xT = torch.randn(B, C, R, R)
+        y = labels_for(cfg, B)
+        kwargs = {'y': y} if y is not None else {}
+        if case.get('guidance') == 'classifier_free':
+            kwargs = {'y': torch.tensor([1, 2])}
+            y = kwargs['y']
+        # free-running loop with captured noise: patch torch.randn_like to record the draws (step order S-1..0)
+        torch.manual_seed(1)
+        noises = torch.randn(S, B, C, R, R)
+        it = {'i': S - 1}
+        orig = torch.randn_like
+
+        def fake_randn_like(z, *a, **k):
+            n = noises[it['i']]
+            it['i'] -= 1
+            return n.clone()
+        torch.randn_like = fake_randn_like
+        traj = []
+        try:
+            x = xT
+            for tstep in reversed(range(S)):
+                ts = (tstep * torch.ones(B))
+                with torch.no_grad():
+                    if case['ddim']:
+                        x, _ = d.ddim_denoising_step(x, ts, kwargs)
+                    else:
+                        x, _ = d.denoising_step(x, ts, kwargs)
+                traj.append(x.clone())
+            # and once through the public denoise() for the same result
+            it['i'] = S - 1
+            out = d.denoise(x=xT, kwargs=kwargs, batch_size=B, progress=False)
+        finally:
+            torch.randn_like = orig
+        assert torch.equal(out, traj[-1])
+        # oracle check
+        sch = DO.Schedule(1000, S, case['sched'])
+        so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), sch, case['var'],
+                              use_ddim=case['ddim'], ddim_eta=case.get('eta'),
+                              guidance_method=case.get('guidance'), guidance_strength=case.get('w'))
+        otraj = []
+        so.denoise(xT, y, noises=noises, trace=otraj)
+        e0 = (otraj[0] - traj[0]).abs().max().item()
+        eN = (otraj[-1] - traj[-1]).abs().max().item()
+        print('  ', name, 'oracle-vs-reference first-step', e0, 'final', eN, 'final absmax', out.abs().max().item())
+        assert e0 < 1e-5 and eN < 1e-3, (name, e0, eN)
+        arrs = dict(xT=xT.numpy(), noises=noises.numpy(), traj=torch.stack(traj).numpy())
+        if y is not None:
+            arrs['y'] = y.numpy()
+        save('sampler_{}.npz'.format(name), **arrs)
+
+
+# ------------------------------------------------------------------------------------------------ config 1 end-to-end
+def gen_config1():
+    """BASELINE config[0]: EMNIST preset model, 50-step DDIM eta=0, B=4, CPU (SURVEY 8(d) Config 1)."""
+    cfg = dict(ref_presets.EMNIST_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    d = Diffusion(m, 1000, 50, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0,
+                  device=torch.device('cpu'))
+    torch.manual_seed(0)
+    xT = torch.randn(4, 1, 28, 28)
+    y = (torch.arange(4) * 37) % 27
+    out = d.denoise(x=xT, kwargs={'y': y}, batch_size=4, progress=False)
+    sch = DO.Schedule(1000, 50, 'cosine')
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), sch, 'learned_interpolation',
+                          use_ddim=True, ddim_eta=0.0)
+    o = so.denoise(xT, y)
+    err = (o - out).abs().max().item()
+    print('   config1 oracle-vs-reference', err, 'absmax', out.abs().max().item())
+    assert err < 1e-3
+    u8 = ((out + 1) * 127.5).clamp(0, 255).to(torch.uint8)              # sample.py:94 + :164
+    save('config1_emnist_ddim50.npz', xT=xT.numpy(), y=y.numpy(), out=out.numpy(), u8=u8.numpy())
+
+
+# ------------------------------------------------------------------------------------------------ CLI dicts (A12)
+def gen_cli():
+    res = {}
+    for name, argv in CLI_CASES.items():
+        parser = make_argparser('diff_sample')
+        args = parser.parse_args(argv)
+        other, margs, dargs = get_dicts_from_args(args)
+        res[name] = dict(argv=argv, other=other, model=margs, diff=dargs)
+    with open(os.path.join(OUT, 'cli_dicts.json'), 'w') as f:
+        json.dump(res, f, indent=1, default=lambda o: list(o))
+    print('wrote cli_dicts.json', list(res))
+
+
+# ------------------------------------------------------------------------------------------------ embedding known answers
+def gen_embed():
+    from nicediffusion.model import timestep_embedding
+    t = torch.tensor([0, 2, 10, 498, 998])
+    save('timestep_embedding.npz', t=t.numpy(), e192=timestep_embedding(t, 192).numpy(),
+         e64=timestep_embedding(t, 64).numpy(), e33=timestep_embedding(t, 33).numpy())
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets']
+    fns = dict(schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
+               samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets)
+    for w in which:
+        print('==', w)
+        fns[w]()
