@@ -1,0 +1,155 @@
+/*
+ * nd_hip.h -- C ABI of libnd_hip.so: the MI355X (gfx950) kernels behind the nice-diffusion sampling hot path.
+ *
+ * The reference (edogariu/nice-diffusion) has no FFI: its hot path is a chain of PyTorch ops.  Each entry point
+ * below replaces one such chain (cited as /root/reference file:line) and is what a ctypes/cffi binding binds.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer (tensor.data_ptr()); no ownership is transferred;
+ *   - activations are fp32 NHWC ("pixel-major"): element (img, y, x, c) lives at ((img*H + y)*W + x)*ld + c,
+ *     with ld >= C the pixel stride in floats; ld and every channel count handed to a vector kernel are
+ *     multiples of 4 and base pointers are 16-byte aligned;
+ *   - every launch is asynchronous on `stream` (a hipStream_t), allocation-free and sync-free, so that a
+ *     caller may capture it into a hipGraph;
+ *   - return value: 0 = ok, < 0 = error (ND_E_*), message via nd_last_error() (thread-local); nothing throws.
+ */
+#ifndef ND_HIP_H
+#define ND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nd_stream_t; /* hipStream_t */
+
+#define ND_OK 0
+#define ND_E_ARG (-1)     /* bad argument (shape / alignment / unsupported combination) */
+#define ND_E_LAUNCH (-2)  /* HIP launch error */
+#define ND_E_ARCH (-3)    /* device is not gfx950 */
+
+/* flags for nd_conv_nhwc */
+#define ND_CONV_IN_UP2X 1   /* input is stored at half resolution and read through nearest-2x upsampling */
+#define ND_CONV_RES_UP2X 2  /* residual is stored at half resolution and read through nearest-2x upsampling */
+#define ND_CONV_SILU_OUT 4  /* apply SiLU to the result (after bias; residual must be NULL) */
+
+/* flags for nd_groupnorm_apply_nhwc */
+#define ND_GN_SILU 1        /* SiLU after the affine */
+#define ND_GN_POOL2 2       /* write the 2x2 average of the activated values ([NI,H/2,W/2,C]) */
+
+/* sampler variance kinds for nd_ddpm_step (reference: VarType, diffusion.py:552-572) */
+#define ND_VAR_FIXED 0          /* 'small' / 'large': log-variance comes from coef column 6 */
+#define ND_VAR_LEARNED 1        /* model output second half is the log-variance */
+#define ND_VAR_LEARNED_INTERP 2 /* second half interpolates between coef columns 6 (min) and 7 (max) */
+
+#define ND_COEF_COLS 8 /* per-step fp32 coefficient row: see nd_ddim_step / nd_ddpm_step */
+
+int nd_version(void);
+const char* nd_last_error(void);
+/* gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-"); "" on error. */
+const char* nd_device_arch(void);
+
+/* ---- K1: sinusoidal timestep embedding (model.py:514-523): out[b] = [cos(t*f) | sin(t*f) | 0 pad] ----------
+ * freqs [dim/2] is the constant fp32 table exp(arange(dim/2) * -(ln 10000)/(dim/2)) (model.py:516-517). */
+int nd_timestep_embed(const int64_t* t, const float* freqs, int B, int dim, float* out, int ld_out,
+                      nd_stream_t stream);
+
+/* emb[b,:] += table[y[b],:] (y may be NULL), then silu_out[b,:] = silu(emb[b,:])  (model.py:459, :197 input) */
+int nd_embedding_add_silu(float* emb, const float* table, const int64_t* y, int num_rows, int B, int D,
+                          float* silu_out, nd_stream_t stream);
+
+/* ---- K5/K6/K2: convolution as an implicit GEMM on fp32 MFMA ------------------------------------------------
+ * out[img,y,x,n] = bias[n] + rowbias[img,n] + sum_{tap,c} in(img, y+dy-1, x+dx-1, c) * w[tap][n][c] + residual
+ *   ksize 3: nn.Conv2d 3x3 stride 1 pad 1 (model.py:173,177,367,448,72);  ksize 1: nn.Conv2d 1x1 / nn.Conv1d k=1 /
+ *   nn.Linear (model.py:169,247,253,180,349-351) -- for those pass NI=1, H=1, W=M.
+ *   The input is the channel concatenation of x0 (C0 channels, stride ldx0) and x1 (C1, ldx1) (torch.cat,
+ *   model.py:474); x1 may be NULL with C1 = 0.  If C1 > 0, C0 must be a multiple of 32.
+ *   w is [ksize*ksize][N][ldw] fp32 (tap-major, input channel contiguous; see nd_repack_conv_weight), ldw >= C0+C1.
+ *   bias [N] | NULL;  rowbias [NI][ld_rowbias] | NULL (per-image bias: the timestep embedding of model.py:205);
+ *   residual [NI,H,W,N] stride ldr | NULL (model.py:211, :291).  `variant` < 0 selects the tile shape automatically.
+ */
+int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                 const float* w, int ldw, const float* bias, const float* rowbias, int ld_rowbias,
+                 const float* residual, int ldr, float* out, int ldo,
+                 int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream);
+
+/* Number of tile-shape variants nd_conv_nhwc accepts for `variant` (0 .. n-1). */
+int nd_conv_num_variants(void);
+
+/* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
+ * (Downsample with_conv, model.py:103-105).  w layout as above.  out is [NI, Ho, Wo, N]. */
+int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+                        float* out, int ldo, int NI, int H, int W, int N, int ksize, int stride, int pad,
+                        nd_stream_t stream);
+
+/* OIHW [N][C][k][k] -> [k*k][N][ldw] (zero-filled for c >= C); run once at load_state_dict time. */
+int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, int ldw, nd_stream_t stream);
+
+/* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1) ------------------------------------------
+ * stats: accumulates per (img, group) sum and sum of squares of (x + addvec[img,c]) in float64 into
+ *   stats[NI][G][2]; the caller zeroes `stats` beforehand (hipMemsetAsync).  addvec [NI][ld_add] | NULL is the
+ *   non-adaptive timestep-embedding add that precedes out_norm (model.py:205).
+ * apply: y = ((x+addvec) - mean) * rstd * gamma + beta;  if scale: y = y*(1+scale[img,c]) + shift[img,c]
+ *   (model.py:201-203); optional SiLU (model.py:190,207,447); optional 2x2 average pool of the result
+ *   (model.py:111 applied to h, :192).  eps as nn.GroupNorm (1e-5).
+ */
+int nd_groupnorm_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                            const float* addvec, int ld_add, double* stats, int NI, int HW, int G,
+                            nd_stream_t stream);
+int nd_groupnorm_apply_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                            const float* addvec, int ld_add, const double* stats,
+                            const float* gamma, const float* beta,
+                            const float* scale, const float* shift, int ld_ss,
+                            float* out, int ldo, int NI, int H, int W, int G, float eps, int flags,
+                            nd_stream_t stream);
+
+/* ---- K7: attention core softmax(q k^T * scale) v over T tokens (model.py:266-287) ---------------------------
+ * qkv is [B*T][ld_qkv]; head h reads q at column q_off + h*head_stride + d, k at k_off + ..., v at v_off + ...
+ *   split_qkv_first=True : q_off=0, k_off=C,  v_off=2C,  head_stride=hd      (model.py:268-270)
+ *   split_qkv_first=False: q_off=0, k_off=hd, v_off=2hd, head_stride=3*hd    (model.py:279-280)
+ * out is [B*T][ld_out] with column h*hd + d.  hd must be a multiple of 8 and <= 256.
+ */
+int nd_attention_nhwc(const float* qkv, int ld_qkv, float* out, int ld_out, int B, int T, int heads, int hd,
+                      int q_off, int k_off, int v_off, int head_stride, float scale, nd_stream_t stream);
+
+/* ---- K8: standalone 2x resampling (Upsample/Downsample without conv, model.py:77,111; x path of :193) ------- */
+int nd_upsample2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
+int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
+
+/* ---- layout at the API edge: NCHW [NI][C][HW] <-> NHWC [NI][HW][ld] (pad channels written as 0) ------------- */
+int nd_nchw_to_nhwc(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream);
+int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream);
+
+/* ---- K10: sampler updates (device-side step index so the step body is hipGraph-capturable) ------------------
+ * step: device int32, the current rescaled index t.  coef: fp32 [S][ND_COEF_COLS], row t =
+ *   { sqrt(1/abar_t), sqrt(1/abar_t - 1), abar_t, abar_{t-1}, posterior_mean_coef_x0, posterior_mean_coef_xt,
+ *     logvar_a, logvar_b }  (float64 tables of diffusion.py:115-130 cast to fp32 as extract() does, :492).
+ * x, x_out: NHWC [B][HW][ldx] (C channels used); eps / eps_uncond: model output NHWC [B][HW][ld_eps], channels
+ *   [0,C) = epsilon, [C,2C) = variance head.  eps_uncond != NULL applies classifier-free guidance
+ *   eps = (1+w)*eps - w*eps_uncond (diffusion.py:284,347).
+ * noise: NHWC like x, indexed noise + t*noise_step_stride (floats) | NULL.  If NULL and noise is needed
+ *   (eta != 0 / DDPM) it is drawn in-kernel from Philox4x32-10 keyed by (seed, t, element).
+ */
+int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step, int64_t* t_out, int B, nd_stream_t stream);
+int nd_step_advance(int32_t* step, int delta, nd_stream_t stream);
+int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
+                 float guidance_w, const float* coef, const int32_t* step, float eta,
+                 const float* noise, int64_t noise_step_stride, uint64_t seed,
+                 int B, int HW, int C, nd_stream_t stream);
+int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
+                 float guidance_w, const float* coef, const int32_t* step, int var_kind,
+                 const float* noise, int64_t noise_step_stride, uint64_t seed,
+                 int B, int HW, int C, nd_stream_t stream);
+/* forward diffusion q(x_t | x_0) = sqrt(abar_t) x0 + sqrt(1-abar_t) noise (diffusion.py:232-240) */
+int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,
+               nd_stream_t stream);
+
+/* ---- N2: image post-processing ((x+1)*127.5).clamp(0,255) -> uint8 (truncation), NHWC -> HWC bytes,
+ * optional grayscale inversion 255-v (scripts/sample.py:94-100,164-171). */
+int nd_to_uint8_hwc(const float* x, int ldx, uint8_t* out, int NI, int HW, int C, int invert, nd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ND_HIP_H */

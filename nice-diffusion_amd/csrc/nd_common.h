@@ -1,0 +1,43 @@
+// Shared helpers for libnd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "nd_hip.h"
+
+namespace nd {
+
+void set_error(const char* fmt, ...);
+
+inline int fail_arg(const char* fn, const char* what) {
+    set_error("%s: %s", fn, what);
+    return ND_E_ARG;
+}
+
+inline int check_launch(const char* fn) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", fn, hipGetErrorString(e));
+        return ND_E_LAUNCH;
+    }
+    return ND_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define ND_REQUIRE(cond, fn, msg) \
+    do {                          \
+        if (!(cond)) return nd::fail_arg(fn, msg); \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float fast_silu(float v) {
+    // v * sigmoid(v); v_exp_f32 + v_rcp_f32 (about 1 ulp each)
+    return v * __frcp_rn(1.0f + __expf(-v));
+}
+
+}  // namespace nd

@@ -1,0 +1,260 @@
+// HBM-bound / tiny kernels around the UNet: timestep embedding (K1), resampling (K8), layout conversion at the
+// API edge, weight repack, the direct stride-2 convolution, and uint8 image conversion (N2).
+#include "nd_common.h"
+
+namespace nd {
+
+// ---- K1: model.py:514-523 ------------------------------------------------------------------------------------
+// freqs[k] = exp(k * -(ln(10000)/half)) is a constant fp32 table built once by the host (model.py:516-517)
+__global__ void timestep_embed_kernel(const int64_t* t, const float* freqs, int B, int dim, float* out, int ld) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim) return;
+    const int half = dim >> 1;
+    float v = 0.f;   // zero pad for odd dims
+    if (i < 2 * half) {
+        const int k = (i < half) ? i : i - half;
+        const float arg = (float)t[b] * freqs[k];
+        v = (i < half) ? cosf(arg) : sinf(arg);
+    }
+    out[(size_t)b * ld + i] = v;
+}
+
+__global__ void embedding_add_silu_kernel(float* emb, const float* table, const int64_t* y, int num_rows, int D,
+                                          float* silu_out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    float v = emb[(size_t)b * D + i];
+    if (table) {
+        int64_t r = y[b];
+        r = r < 0 ? 0 : (r >= num_rows ? num_rows - 1 : r);
+        v += table[(size_t)r * D + i];
+        emb[(size_t)b * D + i] = v;
+    }
+    if (silu_out) {
+        // accurate SiLU here: 38 linears hang off this vector
+        silu_out[(size_t)b * D + i] = v / (1.0f + expf(-v));
+    }
+}
+
+// ---- K8 ------------------------------------------------------------------------------------------------------
+__global__ void upsample2x_kernel(const float* x, int ldx, float* out, int ldo, int H, int W, int CQ, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int qd = (int)(it % CQ);
+        long pix = it / CQ;                       // output pixel index over [NI, 2H, 2W]
+        const int ox = (int)(pix % (2 * W));
+        pix /= (2 * W);
+        const int oy = (int)(pix % (2 * H));
+        const long img = pix / (2 * H);
+        const size_t src = ((size_t)(img * H + (oy >> 1)) * W + (ox >> 1)) * ldx + qd * 4;
+        const size_t dst = ((size_t)(img * 2 * H + oy) * (2 * W) + ox) * ldo + qd * 4;
+        *reinterpret_cast<f32x4*>(out + dst) = *reinterpret_cast<const f32x4*>(x + src);
+    }
+}
+
+__global__ void avgpool2x_kernel(const float* x, int ldx, float* out, int ldo, int H, int W, int CQ, long total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int qd = (int)(it % CQ);
+        long pix = it / CQ;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const long img = pix / Ho;
+        const size_t s0 = ((size_t)(img * H + 2 * oy) * W + 2 * ox) * ldx + qd * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + s0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(x + s0 + ldx);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(x + s0 + (size_t)W * ldx);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(x + s0 + (size_t)W * ldx + ldx);
+        const size_t dst = ((size_t)(img * Ho + oy) * Wo + ox) * ldo + qd * 4;
+        *reinterpret_cast<f32x4*>(out + dst) = (a + b + c + d) * 0.25f;
+    }
+}
+
+// ---- layout --------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int C, int HW, int ld, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % ld);
+        const long pix = it / ld;                 // img*HW + p
+        const long img = pix / HW;
+        const int p = (int)(pix - img * HW);
+        dst[it] = (c < C) ? src[((size_t)img * C + c) * HW + p] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int C, int HW, int ld, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(it % HW);
+        const long ic = it / HW;                  // img*C + c
+        const long img = ic / C;
+        const int c = (int)(ic - img * C);
+        dst[it] = src[((size_t)img * HW + p) * ld + c];
+    }
+}
+
+// ---- weights -------------------------------------------------------------------------------------------------
+__global__ void repack_conv_weight_kernel(const float* w, float* out, int N, int C, int taps, int ldw, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % ldw);
+        long r = it / ldw;
+        const int n = (int)(r % N);
+        const int tap = (int)(r / N);
+        out[it] = (c < C) ? w[((size_t)n * C + c) * taps + tap] : 0.f;
+    }
+}
+
+// ---- direct convolution (one thread per output element; only for the non-preset stride-2 Downsample conv) -----
+__global__ void conv_direct_kernel(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+                                   float* out, int ldo, int H, int W, int Ho, int Wo, int N, int ks, int stride,
+                                   int pad, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(it % N);
+        long pix = it / N;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const long img = pix / Ho;
+        float acc = bias ? bias[n] : 0.f;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float* xp = x + ((size_t)(img * H + iy) * W + ix) * ldx;
+                const float* wp = w + ((size_t)(ky * ks + kx) * N + n) * ldw;
+                for (int c = 0; c < C; c += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + c);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(wp + c);
+                    acc = fmaf(a[0], b[0], acc);
+                    acc = fmaf(a[1], b[1], acc);
+                    acc = fmaf(a[2], b[2], acc);
+                    acc = fmaf(a[3], b[3], acc);
+                }
+            }
+        }
+        out[((size_t)(img * Ho + oy) * Wo + ox) * ldo + n] = acc;
+    }
+}
+
+// ---- N2: scripts/sample.py:94-100,164-171 --------------------------------------------------------------------
+__global__ void to_uint8_kernel(const float* x, int ldx, uint8_t* out, int C, int invert, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % C);
+        const long pix = it / C;
+        float v = (x[(size_t)pix * ldx + c] + 1.0f) * 127.5f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        if (invert) v = 255.0f - v;
+        out[it] = (uint8_t)v;   // truncation, as tensor.to(torch.uint8)
+    }
+}
+
+static inline int grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace nd
+
+using namespace nd;
+
+#define ND_STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int nd_timestep_embed(const int64_t* t, const float* freqs, int B, int dim, float* out, int ld_out,
+                                 nd_stream_t stream) {
+    const char* fn = "nd_timestep_embed";
+    ND_REQUIRE(t && freqs && out && B > 0 && dim > 1 && ld_out >= dim, fn, "bad arguments");
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((dim + 127) / 128, B), dim3(128), 0, ND_STREAM(stream), t, freqs, B,
+                       dim, out, ld_out);
+    return check_launch(fn);
+}
+
+extern "C" int nd_embedding_add_silu(float* emb, const float* table, const int64_t* y, int num_rows, int B, int D,
+                                     float* silu_out, nd_stream_t stream) {
+    const char* fn = "nd_embedding_add_silu";
+    ND_REQUIRE(emb && B > 0 && D > 0, fn, "bad arguments");
+    ND_REQUIRE((table == nullptr) == (y == nullptr), fn, "table and y go together");
+    hipLaunchKernelGGL(embedding_add_silu_kernel, dim3((D + 127) / 128, B), dim3(128), 0, ND_STREAM(stream), emb,
+                       table, y, num_rows, D, silu_out);
+    return check_launch(fn);
+}
+
+extern "C" int nd_upsample2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C,
+                                  nd_stream_t stream) {
+    const char* fn = "nd_upsample2x_nhwc";
+    ND_REQUIRE(x && out && NI > 0 && H > 0 && W > 0 && C > 0, fn, "bad arguments");
+    ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && aligned16(x) && aligned16(out), fn, "alignment");
+    const long total = (long)NI * 4 * H * W * (C >> 2);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out,
+                       ldo, H, W, C >> 2, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C,
+                                 nd_stream_t stream) {
+    const char* fn = "nd_avgpool2x_nhwc";
+    ND_REQUIRE(x && out && NI > 0 && H > 1 && W > 1 && C > 0, fn, "bad arguments");
+    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "H and W must be even");
+    ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && aligned16(x) && aligned16(out), fn, "alignment");
+    const long total = (long)NI * (H >> 1) * (W >> 1) * (C >> 2);
+    hipLaunchKernelGGL(avgpool2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out,
+                       ldo, H, W, C >> 2, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_nchw_to_nhwc(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream) {
+    const char* fn = "nd_nchw_to_nhwc";
+    ND_REQUIRE(src && dst && NI > 0 && C > 0 && HW > 0 && ld >= C, fn, "bad arguments");
+    const long total = (long)NI * HW * ld;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C,
+                       HW, ld, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream) {
+    const char* fn = "nd_nhwc_to_nchw";
+    ND_REQUIRE(src && dst && NI > 0 && C > 0 && HW > 0 && ld >= C, fn, "bad arguments");
+    const long total = (long)NI * C * HW;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C,
+                       HW, ld, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, int ldw,
+                                     nd_stream_t stream) {
+    const char* fn = "nd_repack_conv_weight";
+    ND_REQUIRE(w_oihw && w_out && N > 0 && C > 0 && ksize > 0 && ldw >= C, fn, "bad arguments");
+    const int taps = ksize * ksize;
+    const long total = (long)taps * N * ldw;
+    hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), w_oihw,
+                       w_out, N, C, taps, ldw, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+                                   float* out, int ldo, int NI, int H, int W, int N, int ksize, int stride, int pad,
+                                   nd_stream_t stream) {
+    const char* fn = "nd_conv_direct_nhwc";
+    ND_REQUIRE(x && w && out && NI > 0 && H > 0 && W > 0 && N > 0 && C > 0, fn, "bad arguments");
+    ND_REQUIRE(ksize >= 1 && stride >= 1 && pad >= 0, fn, "bad conv geometry");
+    ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && aligned16(x) && aligned16(w), fn, "alignment");
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    ND_REQUIRE(Ho > 0 && Wo > 0 && ldo >= N, fn, "bad output shape");
+    const long total = (long)NI * Ho * Wo * N;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, C, ldx, w,
+                       ldw, bias, out, ldo, H, W, Ho, Wo, N, ksize, stride, pad, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_to_uint8_hwc(const float* x, int ldx, uint8_t* out, int NI, int HW, int C, int invert,
+                               nd_stream_t stream) {
+    const char* fn = "nd_to_uint8_hwc";
+    ND_REQUIRE(x && out && NI > 0 && HW > 0 && C > 0 && ldx >= C, fn, "bad arguments");
+    const long total = (long)NI * HW * C;
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out, C,
+                       invert, total);
+    return check_launch(fn);
+}

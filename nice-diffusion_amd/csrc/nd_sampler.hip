@@ -1,0 +1,206 @@
+// K10: per-step sampler updates of the reverse loop, fused into one HBM pass each.
+//   nd_ddim_step  <- Diffusion.ddim_denoising_step     diffusion.py:324-367 (everything after the model call)
+//   nd_ddpm_step  <- Diffusion.denoising_step + get_eps_and_log_var   diffusion.py:248-314
+//   nd_qsample    <- Diffusion.diffusion_step          diffusion.py:232-240
+// The reference gathers 4-6 per-step scalars with extract() (diffusion.py:478-496: a host->device copy of a whole
+// float64 table, .float(), gather) per call.  Here the tables live on the device as one fp32 row per step and the
+// step index itself is a device word, so the whole step body can be captured in a hipGraph and replayed.
+// Arithmetic follows the reference's fp32 operation order so teacher-forced steps agree to rounding.
+#include "nd_common.h"
+
+namespace nd {
+
+// ---- Philox4x32-10 + Box-Muller: counter-based N(0,1), no state in memory --------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// one N(0,1) draw for element `idx` of step `t`
+__device__ __forceinline__ float philox_normal(uint64_t seed, int t, uint64_t idx) {
+    uint32_t r[4];
+    philox4x32_10(seed, idx >> 1, (uint64_t)(uint32_t)t, r);
+    const float u1 = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
+    const float u2 = (float)r[1] * 2.3283064365386963e-10f;            // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    return (idx & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+struct StepArgs {
+    const float* x;
+    float* x_out;
+    const float* eps;
+    const float* eps_u;
+    const float* coef;
+    const int32_t* step;
+    const float* noise;
+    int64_t noise_stride;
+    uint64_t seed;
+    int ldx, ld_eps, HW, C;
+    float w, eta;
+    int var_kind;
+    long total;   // B*HW*C
+};
+
+__device__ __forceinline__ float guided_eps(const StepArgs& a, size_t pe, int c) {
+    float e = a.eps[pe + c];
+    if (a.eps_u) e = (1.0f + a.w) * e - a.w * a.eps_u[pe + c];          // diffusion.py:284 / :347
+    return e;
+}
+
+__global__ void __launch_bounds__(256) ddim_step_kernel(const StepArgs a) {
+    const int t = *a.step;
+    const float* cf = a.coef + (size_t)t * ND_COEF_COLS;
+    const float c_rec = cf[0], c_recm1 = cf[1], ab = cf[2], abp = cf[3];
+    // diffusion.py:359-360, fp32 like the reference's tensors
+    const float var = a.eta * a.eta * (1.0f - abp) * (1.0f - ab / abp) / (1.0f - ab);
+    const float s_abp = sqrtf(abp);
+    const float s_dir = sqrtf(1.0f - abp - var);
+    const float sigma = (t != 0) ? sqrtf(var) : 0.0f;                  // mask = (t != 0)
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < a.total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % a.C);
+        const long pix = it / a.C;
+        const size_t px = (size_t)pix * a.ldx + c;
+        const float xt = a.x[px];
+        const float e = guided_eps(a, (size_t)pix * a.ld_eps, c);
+        float x0 = c_rec * xt - c_recm1 * e;                             // :350-351
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                              // :353
+        float v = x0 * s_abp + s_dir * e;                                // :360
+        if (sigma != 0.0f) {
+            const float nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
+            v += sigma * nz;                                             // :366
+        }
+        a.x_out[px] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) ddpm_step_kernel(const StepArgs a) {
+    const int t = *a.step;
+    const float* cf = a.coef + (size_t)t * ND_COEF_COLS;
+    const float c_rec = cf[0], c_recm1 = cf[1], c_x0 = cf[4], c_xt = cf[5], lv_a = cf[6], lv_b = cf[7];
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < a.total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % a.C);
+        const long pix = it / a.C;
+        const size_t px = (size_t)pix * a.ldx + c;
+        const size_t pe = (size_t)pix * a.ld_eps;
+        const float xt = a.x[px];
+        const float e = guided_eps(a, pe, c);
+        float log_var;
+        if (a.var_kind == ND_VAR_LEARNED) {
+            log_var = a.eps[pe + a.C + c];                               // :249
+        } else if (a.var_kind == ND_VAR_LEARNED_INTERP) {
+            const float frac = (a.eps[pe + a.C + c] + 1.0f) / 2.0f;      // :256
+            log_var = frac * lv_b + (1.0f - frac) * lv_a;                // :257 (max_log = lv_b, min_log = lv_a)
+        } else {
+            log_var = lv_a;                                              // :259 / :261
+        }
+        float x0 = c_rec * xt - c_recm1 * e;                             // :287-288
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                              // :290
+        float v = c_x0 * x0 + c_xt * xt;                                 // :293-294
+        if (t != 0) {
+            const float nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
+            v += expf(0.5f * log_var) * nz;                              // :313
+        }
+        a.x_out[px] = v;
+    }
+}
+
+__global__ void qsample_kernel(const float* x0, const float* noise, float* out, long n, float a, float b) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a * x0[i] + b * noise[i];
+}
+
+__global__ void fill_timestep_kernel(const int64_t* tmap, const int32_t* step, int64_t* t_out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) t_out[i] = tmap[*step];
+}
+
+__global__ void step_advance_kernel(int32_t* step, int delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += delta;
+}
+
+static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, int ldx, const float* eps,
+                       const float* eps_u, int ld_eps, float w, const float* coef, const int32_t* step, float eta,
+                       int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, int B, int HW, int C,
+                       nd_stream_t stream) {
+    ND_REQUIRE(x && x_out && eps && coef && step, fn, "null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && ldx >= C, fn, "bad shape");
+    const int need = (!ddim && var_kind != ND_VAR_FIXED) ? 2 * C : C;
+    ND_REQUIRE(ld_eps >= need, fn, "model output has too few channels for this variance kind");
+    ND_REQUIRE(var_kind >= 0 && var_kind <= 2, fn, "bad var_kind");
+    StepArgs a;
+    a.x = x; a.x_out = x_out; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
+    a.noise_stride = noise_stride; a.seed = seed; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
+    a.eta = eta; a.var_kind = var_kind; a.total = (long)B * HW * C;
+    long g = (a.total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ddim)
+        hipLaunchKernelGGL(ddim_step_kernel, dim3((int)g), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(ddpm_step_kernel, dim3((int)g), dim3(256), 0, s, a);
+    return check_launch(fn);
+}
+
+}  // namespace nd
+
+using namespace nd;
+
+extern "C" int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
+                            int ld_eps, float guidance_w, const float* coef, const int32_t* step, float eta,
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, int B, int HW, int C,
+                            nd_stream_t stream) {
+    return launch_step(true, "nd_ddim_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, eta,
+                       ND_VAR_FIXED, noise, noise_step_stride, seed, B, HW, C, stream);
+}
+
+extern "C" int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
+                            int ld_eps, float guidance_w, const float* coef, const int32_t* step, int var_kind,
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, int B, int HW, int C,
+                            nd_stream_t stream) {
+    return launch_step(false, "nd_ddpm_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, 0.f,
+                       var_kind, noise, noise_step_stride, seed, B, HW, C, stream);
+}
+
+extern "C" int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,
+                          nd_stream_t stream) {
+    const char* fn = "nd_qsample";
+    ND_REQUIRE(x0 && noise && out && n > 0, fn, "bad arguments");
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(qsample_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x0, noise,
+                       out, (long)n, sqrt_ab, sqrt_1mab);
+    return check_launch(fn);
+}
+
+extern "C" int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step, int64_t* t_out, int B,
+                                nd_stream_t stream) {
+    const char* fn = "nd_fill_timestep";
+    ND_REQUIRE(timestep_map && step && t_out && B > 0, fn, "bad arguments");
+    hipLaunchKernelGGL(fill_timestep_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), timestep_map, step, t_out, B);
+    return check_launch(fn);
+}
+
+extern "C" int nd_step_advance(int32_t* step, int delta, nd_stream_t stream) {
+    const char* fn = "nd_step_advance";
+    ND_REQUIRE(step != nullptr, fn, "null pointer");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), step, delta);
+    return check_launch(fn);
+}

@@ -1,0 +1,412 @@
+"""Execution plan of one UNet forward on an AMD GPU: a flat list of libnd_hip.so launches over NHWC buffers.
+
+The plan is built once per (model, batch size): weights are repacked into the kernels' layout, every intermediate
+gets a slot in a reuse pool, and every launch becomes a pre-bound ctypes call.  Running the plan is a loop over those
+calls on the current stream; it allocates nothing and never synchronises, so a caller can capture it into a hipGraph
+(``Diffusion.denoise`` does).  Reference counterpart: the module-by-module Python dispatch of
+``DiffusionModel.forward`` (model.py:451-476) and ``UsesStepsSequential.forward`` (model.py:42-48).
+"""
+import math
+
+import torch
+
+from . import _hip
+
+GN_GROUPS = 32
+GN_EPS = 1e-5
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class Act:
+    """NHWC activation: flat fp32 buffer + geometry."""
+    __slots__ = ('t', 'NI', 'H', 'W', 'C', 'ld')
+
+    def __init__(self, t, NI, H, W, C, ld=None):
+        self.t, self.NI, self.H, self.W, self.C = t, NI, H, W, C
+        self.ld = C if ld is None else ld
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class _Pool:
+    """Plan-time buffer reuse: launches are stream-ordered, so a buffer can be handed out again as soon as the plan
+    has emitted its last reader."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = []      # list of (numel, tensor)
+        self.total = 0
+
+    def take(self, numel):
+        best = None
+        for i, (n, t) in enumerate(self.free):
+            if n >= numel and (best is None or n < self.free[best][0]):
+                best = i
+        if best is not None and self.free[best][0] <= 2 * numel:
+            return self.free.pop(best)[1]
+        t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.total += numel
+        return t
+
+    def give(self, t):
+        self.free.append((t.numel(), t))
+
+
+class UNetPlan:
+    def __init__(self, model, NI):
+        self.lib = _hip.load()
+        self.model = model
+        self.NI = NI
+        dev = next(model.parameters()).device
+        _hip.require_device(next(model.parameters()), 'model parameters')
+        _hip.require_gfx950(dev.index if dev.index is not None else torch.cuda.current_device())
+        self.device = dev
+        self.ops = []           # (fn, args, label)
+        self.keep = []          # tensors that must outlive the plan (packed weights, etc.)
+        self.pool = _Pool(dev)
+        self.flops = 0          # algorithmic flops of the MFMA launches (2 per MAC)
+        self.conv_flops = {}    # label -> flops
+        R = model.resolution
+        self.R = R
+        self.Cin = model.in_channels
+        self.Cin_p = _pad4(model.in_channels)
+        self.Cout = model.out_channels
+        self.Cout_p = _pad4(model.out_channels)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # static I/O buffers
+        self.x_in = torch.zeros(NI * R * R * self.Cin_p, **f32)
+        self.t_in = torch.zeros(NI, dtype=torch.int64, device=dev)
+        self.y_in = torch.zeros(NI, dtype=torch.int64, device=dev) if model.conditional else None
+        self.out = torch.empty(NI * R * R * self.Cout_p, **f32)
+        self._gn_slots = 0
+        self._gn_users = []     # ops needing the stats base pointer patched in
+        self._build()
+        self.weight_signature = model._weight_signature()
+
+    # ------------------------------------------------------------------------------------------------ emit helpers
+    def _emit(self, fn, args, label):
+        self.ops.append((fn, tuple(args), label))
+
+    def _new(self, NI, H, W, C):
+        return Act(self.pool.take(NI * H * W * C), NI, H, W, C)
+
+    def _release(self, act):
+        if act is not None and act.t is not None:
+            self.pool.give(act.t)
+
+    def _packed_conv3(self, weight):
+        """OIHW -> [9][N][Cin_pad4] once, on the device."""
+        N, C, k, _ = weight.shape
+        ldw = _pad4(C)
+        out = torch.empty(k * k * N * ldw, dtype=torch.float32, device=self.device)
+        w = weight.detach().contiguous()
+        _hip.check(self.lib.nd_repack_conv_weight(w.data_ptr(), out.data_ptr(), N, C, k, ldw, self._stream()),
+                   'nd_repack_conv_weight')
+        self.keep.append(out)
+        return out, ldw
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def conv(self, src, w_ptr, ldw, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
+             residual=None, flags=0, label='conv'):
+        """Emit nd_conv_nhwc.  ``src`` (and optional ``src2``) are Acts; output spatial size is src's, doubled when
+        CONV_IN_UP2X is set."""
+        up = 1 if (flags & _hip.CONV_IN_UP2X) else 0
+        NI, H, W = src.NI, src.H << up, src.W << up
+        if out is None:
+            out = self._new(NI, H, W, N)
+        C1 = 0 if src2 is None else src2.C
+        args = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld,
+                w_ptr, ldw, bias, rowbias, ld_rowbias,
+                None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
+                out.ptr, out.ld, NI, H, W, N, ksize, flags, -1]
+        self._emit(self.lib.nd_conv_nhwc, args, label)
+        fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
+        self.flops += fl
+        self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
+        return out
+
+    def linear(self, src_ptr, M, K, weight, bias, out_ptr, N, flags=0, label='linear'):
+        w = weight.detach()
+        assert w.is_contiguous() and K % 4 == 0
+        args = [src_ptr, K, K, None, 0, 0, w.data_ptr(), K, None if bias is None else bias.detach().data_ptr(),
+                None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1]
+        self._emit(self.lib.nd_conv_nhwc, args, label)
+        self.flops += 2 * M * N * K
+
+    def groupnorm(self, src, norm, out=None, src2=None, scale_ptr=None, shift_ptr=None, ld_ss=0, silu=True,
+                  pool=False, label='gn'):
+        slot = self._gn_slots
+        self._gn_slots += 1
+        C = src.C + (0 if src2 is None else src2.C)
+        NI, H, W = src.NI, src.H, src.W
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        if out is None:
+            out = self._new(NI, Ho, Wo, C)
+        s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
+        stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS]
+        self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
+        flags = (_hip.GN_SILU if silu else 0) | (_hip.GN_POOL2 if pool else 0)
+        apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot),
+                      norm.weight.detach().data_ptr(), norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
+                      out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags]
+        self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
+        return out
+
+    # ------------------------------------------------------------------------------------------------ build
+    def _build(self):
+        m = self.model
+        lib = self.lib
+        NI, R = self.NI, self.R
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        mc = m.model_channels
+        ed = 4 * mc
+        assert mc % 4 == 0, 'model_channels must be a multiple of 4'
+
+        # ---- K1/K2: timestep embedding MLP, class embedding, and ALL residual blocks' embedding projections at once
+        half = mc // 2
+        self.freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / half)).to(dev)
+        self.temb = torch.zeros(NI * mc, **f32)
+        self.h1 = torch.empty(NI * ed, **f32)
+        self.emb = torch.empty(NI * ed, **f32)
+        self.semb = torch.empty(NI * ed, **f32)
+        self._emit(lib.nd_timestep_embed, [self.t_in.data_ptr(), self.freqs.data_ptr(), NI, mc, self.temb.data_ptr(),
+                                           mc], 'temb')
+        l0, l2 = m.step_embed[0], m.step_embed[2]
+        self.linear(self.temb.data_ptr(), NI, mc, l0.weight, l0.bias, self.h1.data_ptr(), ed,
+                    flags=_hip.CONV_SILU_OUT, label='step_embed.0')
+        self.linear(self.h1.data_ptr(), NI, ed, l2.weight, l2.bias, self.emb.data_ptr(), ed, label='step_embed.2')
+        if m.conditional:
+            tab = m.class_embedding.weight.detach()
+            self._emit(lib.nd_embedding_add_silu, [self.emb.data_ptr(), tab.data_ptr(), self.y_in.data_ptr(),
+                                                   tab.shape[0], NI, ed, self.semb.data_ptr()], 'class_emb')
+        else:
+            self._emit(lib.nd_embedding_add_silu, [self.emb.data_ptr(), None, None, 0, NI, ed,
+                                                   self.semb.data_ptr()], 'emb_silu')
+        res_blocks = m._residual_blocks()
+        widths = [rb.step_embedding.weight.shape[0] for rb in res_blocks]
+        self.e_ld = sum(widths)
+        self.e_off = {}
+        off = 0
+        for rb, wd in zip(res_blocks, widths):
+            self.e_off[id(rb)] = off
+            off += wd
+        if res_blocks:
+            self.e_w = torch.cat([rb.step_embedding.weight.detach() for rb in res_blocks], 0).contiguous()
+            self.e_b = torch.cat([rb.step_embedding.bias.detach() for rb in res_blocks], 0).contiguous()
+            self.e_all = torch.empty(NI * self.e_ld, **f32)
+            args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self.e_w.data_ptr(), ed, self.e_b.data_ptr(),
+                    None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1]
+            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all')
+            self.flops += 2 * NI * self.e_ld * ed
+
+        # ---- the UNet proper
+        x = Act(self.x_in, NI, R, R, self.Cin_p)
+        skips = []
+        # every downsampling block's output is a skip connection: it stays alive until the matching pop below
+        for block in m.downsampling:
+            x = self._run_block(block, x, None, owned=False)
+            skips.append(x)
+        x_cur = self._run_block(m.middle_block, x, None, owned=False)
+        for block in m.upsampling:
+            # torch.cat([x, xs.pop()], 1) of model.py:474 is never materialised: both sources go to the kernels
+            x_cur = self._run_block(block, x_cur, skips.pop(), owned=True, skip_owned=True)
+        # output head: GN -> SiLU -> conv3x3 (model.py:446-449)
+        h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
+        self._release(x_cur)
+        wp, ldw = self._packed_conv3(m.out[2].weight)
+        out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
+        self.conv(h, wp.data_ptr(), ldw, m.out[2].bias.detach().data_ptr(), self.Cout, 3, out=out_act, label='conv3x3')
+        self._release(h)
+
+        # ---- GroupNorm statistics arena (float64 [slots][NI][32][2]); zeroed at the start of every run
+        self.gn_stats = torch.zeros(max(1, self._gn_slots) * NI * GN_GROUPS * 2, dtype=torch.float64, device=dev)
+        slot_bytes = NI * GN_GROUPS * 2 * 8
+        base = self.gn_stats.data_ptr()
+        bound = []
+        for fn, args, label in self.ops:
+            args = tuple(base + a[1] * slot_bytes if (isinstance(a, tuple) and a and a[0] == 'gnstats') else a
+                         for a in args)
+            bound.append((fn, args, label))
+        self.ops = bound
+        self.workspace_floats = self.pool.total
+        self.pool = None
+
+    def _run_block(self, block, x, skip, owned, skip_owned=False):
+        """Run one ``UsesStepsSequential``.  ``skip`` (if given) is concatenated after ``x`` on the channel axis."""
+        from . import model as M
+        cur, cur2 = x, skip
+        cur_owned, cur2_owned = owned, skip_owned
+        for layer in block:
+            if isinstance(layer, M.ResidualBlock):
+                nxt = self._res_block(layer, cur, cur2)
+            elif isinstance(layer, M.AttentionBlock):
+                assert cur2 is None
+                nxt = self._attn_block(layer, cur)
+            elif isinstance(layer, torch.nn.Conv2d):
+                assert cur2 is None
+                wp, ldw = self._packed_conv3(layer.weight)
+                nxt = self.conv(cur, wp.data_ptr(), ldw, layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
+                                label='conv3x3')
+            elif isinstance(layer, M.Downsample):
+                assert cur2 is None
+                nxt = self._downsample(layer, cur)
+            elif isinstance(layer, M.Upsample):
+                assert cur2 is None
+                nxt = self._upsample(layer, cur)
+            else:
+                raise TypeError('unsupported layer {}'.format(type(layer)))
+            if cur_owned:
+                self._release(cur)
+            if cur2 is not None and cur2_owned:
+                self._release(cur2)
+            cur, cur2, cur_owned, cur2_owned = nxt, None, True, False
+        return cur
+
+    def _res_block(self, rb, x, x2):
+        """model.py:188-211."""
+        lib = self.lib
+        NI = x.NI
+        Cin = x.C + (0 if x2 is None else x2.C)
+        Cout = rb.in_conv.weight.shape[0]
+        mode = rb.resample_mode            # None | 'up' | 'down'
+        assert not (mode is not None and x2 is not None)
+        # h = silu(in_norm(x)); 'down' pools here, 'up' is folded into the conv's input addressing
+        h0 = self.groupnorm(x, rb.in_norm, src2=x2, silu=True, pool=(mode == 'down'), label='res.in_norm')
+        e_ptr = self.e_all.data_ptr() + 4 * self.e_off[id(rb)]
+        wp, ldw = self._packed_conv3(rb.in_conv.weight)
+        adaptive = rb.use_adaptive_gn
+        h1 = self.conv(h0, wp.data_ptr(), ldw, rb.in_conv.bias.detach().data_ptr(), Cout, 3,
+                       rowbias=None if adaptive else e_ptr, ld_rowbias=0 if adaptive else self.e_ld,
+                       flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
+        self._release(h0)
+        if adaptive:   # scale = first half, shift = second half (model.py:201)
+            h2 = self.groupnorm(h1, rb.out_norm, scale_ptr=e_ptr, shift_ptr=e_ptr + 4 * Cout, ld_ss=self.e_ld,
+                                silu=True, label='res.out_norm')
+        else:
+            h2 = self.groupnorm(h1, rb.out_norm, silu=True, label='res.out_norm')
+        self._release(h1)
+        # skip path
+        flags = 0
+        res = None
+        tmp = None
+        if mode == 'down':
+            tmp = self._new(NI, x.H // 2, x.W // 2, x.C)
+            self._emit(lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, tmp.ptr, tmp.ld, NI, x.H, x.W, x.C], 'avgpool')
+            xs, xs2 = tmp, None
+        else:
+            xs, xs2 = x, x2
+        if isinstance(rb.skip, torch.nn.Conv2d):
+            k = rb.skip.weight.shape[-1]
+            if k == 1:
+                w = rb.skip.weight.detach()
+                s = self.conv(xs, w.data_ptr(), Cin, rb.skip.bias.detach().data_ptr(), Cout, 1, src2=xs2,
+                              flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv1x1')
+            else:
+                wps, ldws = self._packed_conv3(rb.skip.weight)
+                s = self.conv(xs, wps.data_ptr(), ldws, rb.skip.bias.detach().data_ptr(), Cout, 3, src2=xs2,
+                              flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
+            if tmp is not None:
+                self._release(tmp)
+            tmp = s
+            res = s
+        else:
+            assert xs2 is None and Cin == Cout
+            res = xs
+            if mode == 'up':
+                flags |= _hip.CONV_RES_UP2X
+        wp2, ldw2 = self._packed_conv3(rb.out_conv.weight)
+        out = self.conv(h2, wp2.data_ptr(), ldw2, rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
+                        flags=flags, label='conv3x3')
+        self._release(h2)
+        if tmp is not None:
+            self._release(tmp)
+        return out
+
+    def _attn_block(self, ab, x):
+        """model.py:260-291."""
+        NI, H, W, C = x.NI, x.H, x.W, x.C
+        T = H * W
+        n = self.groupnorm(x, ab.norm, silu=False, label='attn.norm')
+        wq = ab.qkv_nin.weight.detach()
+        qkv = self.conv(n, wq.data_ptr(), C, ab.qkv_nin.bias.detach().data_ptr(), 3 * C, 1, label='conv1x1')
+        self._release(n)
+        a = self._new(NI, H, W, C)
+        nh = ab.num_heads
+        hd = C // nh
+        if ab.split_qkv_first:
+            offs = (0, C, 2 * C, hd)
+        else:
+            offs = (0, hd, 2 * hd, 3 * hd)
+        self._emit(self.lib.nd_attention_nhwc, [qkv.ptr, qkv.ld, a.ptr, a.ld, NI, T, nh, hd, offs[0], offs[1], offs[2],
+                                                offs[3], float(ab.scale)], 'attention')
+        self.flops += 4 * NI * nh * T * T * hd
+        self.conv_flops['attention'] = self.conv_flops.get('attention', 0) + 4 * NI * nh * T * T * hd
+        self._release(qkv)
+        wp = ab.proj_out.weight.detach()
+        out = self.conv(a, wp.data_ptr(), C, ab.proj_out.bias.detach().data_ptr(), C, 1, residual=x, label='conv1x1')
+        self._release(a)
+        return out
+
+    def _downsample(self, layer, x):
+        """model.py:107-112."""
+        NI = x.NI
+        if layer.with_conv:
+            N = layer.conv.weight.shape[0]
+            wp, ldw = self._packed_conv3(layer.conv.weight)
+            Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+            out = self._new(NI, Ho, Wo, N)
+            self._emit(self.lib.nd_conv_direct_nhwc, [x.ptr, x.C, x.ld, wp.data_ptr(), ldw,
+                                                      layer.conv.bias.detach().data_ptr(), out.ptr, out.ld, NI, x.H,
+                                                      x.W, N, 3, 2, 1], 'conv_s2')
+            return out
+        out = self._new(NI, x.H // 2, x.W // 2, x.C)
+        self._emit(self.lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'avgpool')
+        return out
+
+    def _upsample(self, layer, x):
+        """model.py:76-80."""
+        NI = x.NI
+        if layer.with_conv:
+            N = layer.conv.weight.shape[0]
+            wp, ldw = self._packed_conv3(layer.conv.weight)
+            return self.conv(x, wp.data_ptr(), ldw, layer.conv.bias.detach().data_ptr(), N, 3,
+                             flags=_hip.CONV_IN_UP2X, label='conv3x3')
+        out = self._new(NI, 2 * x.H, 2 * x.W, x.C)
+        self._emit(self.lib.nd_upsample2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'upsample')
+        return out
+
+    # ------------------------------------------------------------------------------------------------ run
+    def run(self):
+        """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out."""
+        stream = self._stream()
+        self.gn_stats.zero_()
+        for fn, args, label in self.ops:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
+
+    def run_timed(self):
+        """Eager run with a HIP event pair around every launch; returns [(label, fn name, ms)] (for bench/profiles)."""
+        stream = self._stream()
+        self.gn_stats.zero_()
+        evs = []
+        for fn, args, label in self.ops:
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args, stream)
+            b.record()
+            if rc != 0:
+                raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
+            evs.append((label, fn.__name__, a, b))
+        torch.cuda.synchronize()
+        return [(label, name, a.elapsed_time(b)) for label, name, a, b in evs]

@@ -1,0 +1,129 @@
+"""ctypes binding of ``libnd_hip.so`` (C ABI declared in ``include/nd_hip.h``).
+
+There is no CPU fallback: if the library is missing, cannot be loaded, or the device is not gfx950 the sampling
+path raises.  PyTorch is used only for device memory, streams and graph capture.
+"""
+import ctypes
+import os
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libnd_hip.so')
+
+# flags (mirror include/nd_hip.h)
+CONV_IN_UP2X = 1
+CONV_RES_UP2X = 2
+CONV_SILU_OUT = 4
+GN_SILU = 1
+GN_POOL2 = 2
+VAR_FIXED = 0
+VAR_LEARNED = 1
+VAR_LEARNED_INTERP = 2
+COEF_COLS = 8
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+
+# name -> argtypes; every function returns int status except the three listed in _SPECIAL
+SIGNATURES = {
+    'nd_timestep_embed': [_vp, _vp, _i, _i, _vp, _i, _vp],
+    'nd_embedding_add_silu': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'nd_conv_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
+                     _i, _i, _i, _i, _i, _i, _i, _vp],
+    'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    'nd_groupnorm_apply_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
+                                _i, _i, _i, _i, _f, _i, _vp],
+    'nd_attention_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    'nd_upsample2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_avgpool2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_nchw_to_nhwc': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'nd_nhwc_to_nchw': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'nd_fill_timestep': [_vp, _vp, _vp, _i, _vp],
+    'nd_step_advance': [_vp, _i, _vp],
+    'nd_ddim_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _i, _i, _i, _vp],
+    'nd_ddpm_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _i, _i, _i, _vp],
+    'nd_qsample': [_vp, _vp, _vp, _i64, _f, _f, _vp],
+    'nd_to_uint8_hwc': [_vp, _i, _vp, _i, _i, _i, _i, _vp],
+}
+_SPECIAL = {
+    'nd_version': ([], _i),
+    'nd_conv_num_variants': ([], _i),
+    'nd_last_error': ([], ctypes.c_char_p),
+    'nd_device_arch': ([], ctypes.c_char_p),
+}
+EXPORTS = sorted(list(SIGNATURES) + list(_SPECIAL))
+
+
+class NdHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes library; raises NdHipError if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise NdHipError('libnd_hip.so not found at {} -- build it with `make -C nice-diffusion_amd` '
+                         '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback'
+                         .format(_LIB_PATH))
+    try:
+        L = ctypes.CDLL(_LIB_PATH)
+    except OSError as e:   # pragma: no cover
+        raise NdHipError('cannot load {}: {}'.format(_LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    for name, (argtypes, restype) in _SPECIAL.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _LIB = L
+    return L
+
+
+def last_error():
+    return load().nd_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise NdHipError('{} failed (rc={}): {}'.format(what or 'libnd_hip call', rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_device(t, what='tensor'):
+    if not t.is_cuda:
+        raise NdHipError('{} lives on {}: this build runs the sampling path on an AMD GPU only (no CPU fallback)'
+                         .format(what, t.device))
+
+
+_ARCH_OK = {}
+
+
+def require_gfx950(device_index):
+    """Fail loudly on anything but gfx950 (the kernels use gfx950 MFMA / 160 KiB LDS)."""
+    ok = _ARCH_OK.get(device_index)
+    if ok is None:
+        import torch
+        with torch.cuda.device(device_index):
+            arch = load().nd_device_arch().decode()
+        ok = arch.startswith('gfx950')
+        _ARCH_OK[device_index] = ok
+        if not ok:
+            raise NdHipError('device {} is "{}", libnd_hip.so is built for gfx950 only'.format(device_index, arch))
+    elif not ok:
+        raise NdHipError('device {} is not gfx950'.format(device_index))

@@ -1,0 +1,365 @@
+"""Gaussian diffusion sampler (DDPM / DDIM, classifier-free guidance) with the reverse loop running on the GPU.
+
+Drop-in surface of the reference's ``nicediffusion/diffusion.py`` class ``Diffusion`` for sampling:
+same constructor (diffusion.py:23-28), same public schedule attributes (float64 numpy, diffusion.py:109-130),
+``denoise`` (diffusion.py:156-226) and ``diffuse`` (diffusion.py:133-153).  Differences are all below the surface:
+
+* the per-step scalars live in one fp32 device table and the step index in a device word, instead of 4-6
+  host->device ``extract`` copies per step (diffusion.py:478-496);
+* one step = UNet plan + one fused sampler kernel, captured once as a hipGraph and replayed;
+* x stays NHWC on the device for the whole loop; layout changes happen once at the loop's edges;
+* with ``torch.distributed`` initialised, ``denoise_sharded`` splits the batch over ranks (no communication inside
+  the loop) and all-gathers the finished samples over RCCL.
+
+Training-only pieces of the reference (``loss``, VLB, classifier guidance through autograd) are out of scope.
+"""
+import enum
+import math
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+class VarType(enum.Enum):
+    SMALL = enum.auto()
+    LARGE = enum.auto()
+    LEARNED = enum.auto()
+    LEARNED_INTERPOLATION = enum.auto()
+
+    @staticmethod
+    def get_var_type(name):
+        table = {'small': VarType.SMALL, 'large': VarType.LARGE, 'learned': VarType.LEARNED,
+                 'learned_interpolation': VarType.LEARNED_INTERPOLATION}
+        if name not in table:
+            raise NotImplementedError(name)
+        return table[name]
+
+
+class LossType(enum.Enum):
+    SIMPLE = enum.auto()
+    KL = enum.auto()
+    KL_RESCALED = enum.auto()
+    HYBRID = enum.auto()
+
+    @staticmethod
+    def get_loss_type(name):
+        table = {'simple': LossType.SIMPLE, 'KL': LossType.KL, 'KL_rescaled': LossType.KL_RESCALED,
+                 'hybrid': LossType.HYBRID}
+        if name not in table:
+            raise NotImplementedError(name)
+        return table[name]
+
+
+def get_beta_schedule(schedule_method, num_steps, beta_0, beta_T):
+    """Noise variances for ``num_steps`` steps: 'linear', 'constant' or 'cosine' (IDDPM eq. 17); float64."""
+    if schedule_method == 'linear':
+        return np.linspace(beta_0, beta_T, num_steps, dtype=np.float64)
+    if schedule_method == 'constant':
+        return beta_0 * np.ones(num_steps, dtype=np.float64)
+    if schedule_method == 'cosine':
+        def abar(u):
+            return math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.array([min(1 - abar((i + 1) / num_steps) / abar(i / num_steps), 0.999) for i in range(num_steps)])
+    raise NotImplementedError('unimplemented variance scheduling method: {}'.format(schedule_method))
+
+
+class Diffusion:
+    def __init__(self, model, original_num_steps, rescaled_num_steps, sampling_var_type, loss_type, betas=None,
+                 beta_schedule='linear', guidance_method=None, guidance_strength=None, classifier=None,
+                 use_ddim=False, ddim_eta=None, device=None):
+        self.model = model
+        if device is None:
+            device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        self.device = torch.device(device)
+        self.model.to(self.device)
+        self.model.eval()
+
+        if guidance_method not in (None, 'classifier', 'classifier_free'):
+            raise NotImplementedError(guidance_method)
+        assert guidance_method is None or self.model.conditional, 'can only use guidance if model is conditional'
+        self.guidance = guidance_method
+        self.strength = guidance_strength
+        self.classifier = classifier
+
+        self.original_num_steps = original_num_steps
+        self.rescaled_num_steps = rescaled_num_steps
+        self.sampling_var_type = VarType.get_var_type(sampling_var_type)
+        self.loss_type = LossType.get_loss_type(loss_type)
+        if use_ddim:
+            assert ddim_eta is not None, 'please supply eta if you want to use ddim'
+        self.use_ddim = use_ddim
+        self.ddim_eta = ddim_eta
+
+        # ---- schedule (float64, on the host): respace the T-step chain to the kept steps (IDDPM eq. 19)
+        T, S = original_num_steps, rescaled_num_steps
+        if betas is None:
+            betas = get_beta_schedule(beta_schedule, T, 0.0001 * 1000 / T, 0.02 * 1000 / T)
+        else:
+            assert len(betas) == T, 'betas must be the right length!'
+            betas = np.array(betas, dtype=np.float64)
+        abar_full = np.cumprod(1.0 - betas, axis=0)
+        kept = list(range(T // (2 * S), T + T // (2 * S), T // S))
+        kept_set = set(kept)
+        respaced, prev = [], 1.0
+        for i, a in enumerate(abar_full):
+            if i in kept_set:
+                respaced.append(1.0 - a / prev)
+                prev = a
+        betas = np.array(respaced)
+        assert (betas > 0).all() and (betas <= 1).all(), 'betas in invalid range'
+
+        self.betas = betas
+        self.timestep_map = torch.tensor(kept, device=self.device, dtype=torch.long)
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_reciprocal_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_reciprocal_alphas_minus_one_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_mean_coef_x0 = np.sqrt(self.alphas_cumprod_prev) * betas / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef_xt = np.sqrt(alphas) * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.log_posterior_var_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+
+        self.use_graph = True          # capture the step body as a hipGraph
+        self.seed = None               # Philox seed for in-kernel noise; None -> drawn from torch's CPU generator
+        self._loops = {}
+
+    # ---------------------------------------------------------------------------------------------- device tables
+    def coefficient_table(self):
+        """fp32 [S][8] rows consumed by nd_ddim_step / nd_ddpm_step (column meaning: include/nd_hip.h)."""
+        n = len(self.betas)
+        tab = np.zeros((n, _hip.COEF_COLS), dtype=np.float64)
+        tab[:, 0] = self.sqrt_reciprocal_alphas_cumprod
+        tab[:, 1] = self.sqrt_reciprocal_alphas_minus_one_cumprod
+        tab[:, 2] = self.alphas_cumprod
+        tab[:, 3] = self.alphas_cumprod_prev
+        tab[:, 4] = self.posterior_mean_coef_x0
+        tab[:, 5] = self.posterior_mean_coef_xt
+        vt = self.sampling_var_type
+        if vt == VarType.LEARNED_INTERPOLATION:
+            tab[:, 6] = self.log_posterior_var_clipped
+            tab[:, 7] = np.log(self.betas)
+        elif vt == VarType.LARGE:
+            tab[:, 6] = np.log(np.append(self.posterior_variance[1], self.betas[1:]))
+        elif vt == VarType.SMALL:
+            tab[:, 6] = np.log(np.maximum(self.posterior_variance, 1e-20))
+        return torch.from_numpy(tab).float()
+
+    def _var_kind(self):
+        vt = self.sampling_var_type
+        if vt == VarType.LEARNED:
+            return _hip.VAR_LEARNED
+        if vt == VarType.LEARNED_INTERPOLATION:
+            return _hip.VAR_LEARNED_INTERP
+        return _hip.VAR_FIXED
+
+    @property
+    def _learned(self):
+        return self.sampling_var_type in (VarType.LEARNED, VarType.LEARNED_INTERPOLATION)
+
+    # ---------------------------------------------------------------------------------------------- forward process
+    @torch.no_grad()
+    def diffuse(self, x_0, steps_to_do=None, noise=None):
+        """q(x_t | x_0) after ``steps_to_do`` rescaled steps (reference diffusion.py:133-153, :232-240)."""
+        if steps_to_do is None or steps_to_do > self.rescaled_num_steps:
+            steps_to_do = self.rescaled_num_steps
+        t = steps_to_do - 1
+        x_0 = x_0.to(self.device).float().contiguous()
+        _hip.require_device(x_0, 'x_0')
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        noise = noise.to(self.device).float().contiguous()
+        out = torch.empty_like(x_0)
+        a = float(np.float32(self.sqrt_alphas_cumprod[t]))
+        b = float(np.float32(self.sqrt_one_minus_alphas_cumprod[t]))
+        _hip.check(_hip.load().nd_qsample(x_0.data_ptr(), noise.data_ptr(), out.data_ptr(), x_0.numel(), a, b,
+                                          torch.cuda.current_stream().cuda_stream), 'nd_qsample')
+        return out
+
+    # ---------------------------------------------------------------------------------------------- reverse process
+    @torch.no_grad()
+    def denoise(self, x=None, kwargs=None, start_step=None, steps_to_do=None, batch_size=1, ema_params=None,
+                progress=True, noise=None, trace=None):
+        """Run the reverse chain and return x_0-ish samples [B, C, R, R] (reference diffusion.py:156-226).
+
+        Extra keyword arguments (not in the reference): ``noise`` -- tensor [S, B, C, R, R] with the N(0,1) draw to
+        use at each rescaled step (parity tests; default is in-kernel Philox noise); ``trace`` -- list that receives
+        x after every step (NCHW clones; disables graph replay).
+        """
+        if kwargs is None:
+            kwargs = {}
+        model = self.model
+        assert ('y' in kwargs.keys() and kwargs['y'] is not None) == model.conditional, \
+            'pass label iff model is class-conditional'
+        if model.conditional:
+            assert len(kwargs['y']) == batch_size, 'len(labels) != batch size'
+        if self.guidance == 'classifier':
+            raise NotImplementedError('classifier guidance needs autograd through a classifier (out of scope)')
+
+        original = None
+        if ema_params is not None:      # swap EMA weights in (diffusion.py:185-189)
+            original = {}
+            for name, p in model.named_parameters():
+                original[name] = p.data
+                p.data = ema_params[name].to(self.device)
+        try:
+            if start_step is None:
+                start_step = self.rescaled_num_steps
+            if steps_to_do is None or steps_to_do > start_step:
+                steps_to_do = start_step
+            if x is None:
+                assert start_step == self.rescaled_num_steps, 'cannot start from noise with current step that is not T'
+                x = torch.randn(batch_size, model.in_channels, model.resolution, model.resolution)
+            x = x.to(self.device)
+            _hip.require_device(x, 'x')
+            y = kwargs.get('y')
+            return self._run_loop(x.float().contiguous(), y, steps_to_do, progress, noise, trace)
+        finally:
+            if original is not None:
+                for name, p in model.named_parameters():
+                    p.data = original[name]
+
+    def _run_loop(self, x, y, steps_to_do, progress, noise, trace):
+        model = self.model
+        lib = _hip.load()
+        B = x.shape[0]
+        C, R = model.in_channels, model.resolution
+        HW = R * R
+        cfg = self.guidance == 'classifier_free'
+        NI = 2 * B if cfg else B
+        plan = model._plan(NI)
+        dev = self.device
+        stream = torch.cuda.current_stream().cuda_stream
+        if steps_to_do <= 0:
+            return x.clone()
+
+        key = (id(plan), B)
+        st = self._loops.get(key)
+        if st is None or st['plan'] is not plan:
+            st = dict(plan=plan, coef=self.coefficient_table().to(dev).contiguous(),
+                      tmap=self.timestep_map.to(dev).contiguous(),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, graph_key=None, noise=None)
+            self._loops = {key: st}
+        need_noise = (not self.use_ddim) or (self.ddim_eta != 0)
+        noise_ptr, noise_stride = None, 0
+        if noise is not None and need_noise:
+            assert noise.shape[0] >= steps_to_do and tuple(noise.shape[1:]) == (B, C, R, R), 'noise must be [S,B,C,R,R]'
+            S = noise.shape[0]
+            nb = st['noise']
+            if nb is None or nb.numel() != S * B * HW * plan.Cin_p:
+                nb = torch.empty(S * B * HW * plan.Cin_p, dtype=torch.float32, device=dev)
+                st['noise'] = nb
+                st['graph'] = None
+            nz = noise.to(dev).float().contiguous()
+            _hip.check(lib.nd_nchw_to_nhwc(nz.data_ptr(), nb.data_ptr(), S * B, C, HW, plan.Cin_p, stream),
+                       'nd_nchw_to_nhwc')
+            noise_ptr, noise_stride = nb.data_ptr(), B * HW * plan.Cin_p
+        seed = self.seed
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+
+        # ---- stage inputs: x -> NHWC (padded to 4 channels) in the plan's input buffer; labels; step counter
+        _hip.check(lib.nd_nchw_to_nhwc(x.data_ptr(), plan.x_in.data_ptr(), B, C, HW, plan.Cin_p, stream),
+                   'nd_nchw_to_nhwc')
+        x_state = plan.x_in[:B * HW * plan.Cin_p]
+        if cfg:
+            plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
+        if model.conditional:
+            plan.y_in[:B].copy_(y.to(torch.int64))
+            if cfg:
+                plan.y_in[B:].zero_()              # null class = label 0 (diffusion.py:281,344)
+        st['step'].fill_(steps_to_do - 1)
+
+        eps_ptr = plan.out.data_ptr()
+        eps_u_ptr = plan.out.data_ptr() + 4 * B * HW * plan.Cout_p if cfg else None
+        w = float(self.strength) if cfg else 0.0
+        eta = float(self.ddim_eta) if self.use_ddim else 0.0
+        var_kind = self._var_kind()
+        xp = plan.x_in.data_ptr()
+
+        def body():
+            s = torch.cuda.current_stream().cuda_stream
+            _hip.check(lib.nd_fill_timestep(st['tmap'].data_ptr(), st['step'].data_ptr(), plan.t_in.data_ptr(), NI, s),
+                       'nd_fill_timestep')
+            plan.run()
+            if self.use_ddim:
+                rc = lib.nd_ddim_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                                      st['step'].data_ptr(), eta, noise_ptr, noise_stride, seed, B, HW, C, s)
+            else:
+                rc = lib.nd_ddpm_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                                      st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, seed, B, HW, C, s)
+            _hip.check(rc, 'sampler step')
+            if cfg:
+                plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
+            _hip.check(lib.nd_step_advance(st['step'].data_ptr(), -1, s), 'nd_step_advance')
+
+        def snapshot():
+            o = torch.empty(B, C, R, R, dtype=torch.float32, device=dev)
+            _hip.check(lib.nd_nhwc_to_nchw(xp, o.data_ptr(), B, C, HW, plan.Cin_p,
+                                           torch.cuda.current_stream().cuda_stream), 'nd_nhwc_to_nchw')
+            return o
+
+        steps = range(steps_to_do)
+        bar = None
+        if progress:
+            import tqdm
+            bar = tqdm.tqdm(total=steps_to_do)
+        use_graph = self.use_graph and trace is None and steps_to_do > 1
+        gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, seed if need_noise and noise_ptr is None
+                else 0)
+        done = 0
+        if use_graph:
+            if st['graph'] is None or st['graph_key'] != gkey:
+                body()                               # first step eagerly: warms up lazy kernel attributes
+                done = 1
+                if bar is not None:
+                    bar.update(1)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                st['graph'], st['graph_key'] = g, gkey
+            g = st['graph']
+            for _ in range(done, steps_to_do):
+                g.replay()
+                if bar is not None:
+                    torch.cuda.synchronize()
+                    bar.update(1)
+        else:
+            for _ in steps:
+                body()
+                if trace is not None:
+                    trace.append(snapshot())
+                if bar is not None:
+                    torch.cuda.synchronize()
+                    bar.update(1)
+        if bar is not None:
+            bar.close()
+        return snapshot()
+
+    # ---------------------------------------------------------------------------------------------- multi-GPU
+    @torch.no_grad()
+    def denoise_sharded(self, x, kwargs=None, noise=None, **kw):
+        """Batch-sharded ``denoise``: rank r of N (torch.distributed, RCCL on AMD GPUs) denoises rows
+        [r*B/N, (r+1)*B/N) of the GLOBAL ``x`` / labels / noise and the finished samples are all-gathered, so every
+        rank returns the full [B, C, R, R] result and an N-rank run is comparable row by row with a 1-rank run.
+        The loop itself needs no communication (nothing on the path mixes samples)."""
+        from .parallel import shard_slice, all_gather_rows
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self.denoise(x=x, kwargs=kwargs, batch_size=x.shape[0], noise=noise, **kw)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        sl = shard_slice(x.shape[0], rank, world)
+        lk = None
+        if kwargs is not None:
+            lk = {k: (v[sl] if v is not None else None) for k, v in kwargs.items()}
+        ln = None if noise is None else noise[:, sl]
+        local = self.denoise(x=x[sl], kwargs=lk, batch_size=sl.stop - sl.start, noise=ln, **kw)
+        return all_gather_rows(local, x.shape[0], rank, world)
+
+    def loss(self, *a, **k):
+        raise NotImplementedError('training loss is outside this build (sampling hot path only)')

@@ -1,0 +1,362 @@
+"""Per-kernel parity on a real MI355X: every libnd_hip.so entry point, called through the C ABI (ctypes), against a
+plain fp32 PyTorch-CPU statement of the same reference op.  Tolerances are absolute on O(1) data."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nicediffusion import _hip
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def lib():
+    return _hip.load()
+
+
+def nhwc(x):        # [B,C,H,W] cpu -> flat NHWC on device
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def from_nhwc(t, B, H, W, C):
+    return t.view(B, H, W, C).permute(0, 3, 1, 2).cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def pack_w(w):      # OIHW cpu -> [k*k][N][Cpad] device, via the library's own repack kernel
+    N, C, k, _ = w.shape
+    ldw = (C + 3) // 4 * 4
+    out = torch.empty(k * k * N * ldw, device=DEV)
+    wd = w.contiguous().to(DEV)
+    _hip.check(lib().nd_repack_conv_weight(wd.data_ptr(), out.data_ptr(), N, C, k, ldw, st()))
+    return out, ldw
+
+
+def test_arch_and_version():
+    assert lib().nd_device_arch().decode().startswith('gfx950')
+    _hip.require_gfx950(0)
+
+
+def test_repack_conv_weight():
+    w = rnd(5, 3, 3, 3)
+    out, ldw = pack_w(w)
+    ref = torch.zeros(9, 5, 4)
+    ref[:, :, :3] = w.permute(2, 3, 0, 1).reshape(9, 5, 3)
+    assert torch.equal(out.cpu().view(9, 5, 4), ref)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W
+    (2, 32, 32, 16, 16), (1, 64, 96, 8, 8), (3, 4, 32, 28, 28), (2, 96, 6, 16, 16), (4, 128, 64, 7, 7),
+    (1, 192, 192, 64, 64), (2, 32, 2, 14, 14), (5, 64, 64, 4, 4),
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', CONV_CASES)
+def test_conv3x3_all_variants(B, Cin, Cout, H, W):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    xd, (wd, ldw), bd = nhwc(x), pack_w(w), b.to(DEV)
+    ran = 0
+    for v in [-1] + list(range(lib().nd_conv_num_variants())):
+        out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+        rc = lib().nd_conv_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), ldw, bd.data_ptr(), None, 0, None, 0,
+                                out.data_ptr(), Cout, B, H, W, Cout, 3, 0, v, st())
+        if rc != 0 and v >= 0:
+            continue        # this tile shape does not fit this problem
+        assert rc == 0, _hip.last_error()
+        got = from_nhwc(out, B, H, W, Cout)
+        assert torch.isfinite(got).all(), v
+        assert (got - ref).abs().max().item() < 2e-4, (v, (got - ref).abs().max().item())
+        ran += 1
+    assert ran >= 3
+
+
+def test_conv3x3_fused_options():
+    """two-source concat input, per-image bias, residual, nearest-2x input and residual (model.py:474,205,211,77)."""
+    B, C0, C1, Cout, H, W = 2, 64, 32, 64, 8, 8
+    xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, C1, H, W, seed=2)
+    w, b = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.05), rnd(Cout, seed=4)
+    rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
+    ref = F.conv2d(torch.cat([xa, xb], 1), w, b, padding=1) + rb[:, :, None, None] + res
+    (wd, ldw) = pack_w(w)
+    out = torch.empty(B * H * W * Cout, device=DEV)
+    xad, xbd, bd, rbd, resd = nhwc(xa), nhwc(xb), b.to(DEV), rb.to(DEV), nhwc(res)
+    _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), ldw, bd.data_ptr(),
+                                  rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W, Cout, 3, 0,
+                                  -1, st()))
+    assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
+    # upsampled input + upsampled residual: conv(interp(x)) + interp(r)
+    x, r = rnd(B, C0, H, W, seed=7), rnd(B, Cout, H, W, seed=8)
+    w2 = rnd(Cout, C0, 3, 3, seed=9, scale=0.05)
+    up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
+    ref = F.conv2d(up(x), w2, b, padding=1) + up(r)
+    (wd2, ldw2) = pack_w(w2)
+    out = torch.empty(B * 4 * H * W * Cout, device=DEV)
+    xd, rd = nhwc(x), nhwc(r)
+    _hip.check(lib().nd_conv_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), ldw2, bd.data_ptr(), None, 0,
+                                  rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout, 3,
+                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, -1, st()))
+    assert (from_nhwc(out, B, 2 * H, 2 * W, Cout) - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize('M,K,N', [(2, 32, 128), (64, 768, 1000), (196 * 3, 64, 192), (4096, 384, 1152), (3, 128, 6)])
+def test_gemm_1x1_and_silu(M, K, N):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    ad, wd, bd, resd = a.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV)
+    for v in [-1] + list(range(lib().nd_conv_num_variants())):
+        out = torch.full((M * N,), float('nan'), device=DEV)
+        rc = lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), K, bd.data_ptr(), None, 0,
+                                resd.data_ptr(), N, out.data_ptr(), N, 1, 1, M, N, 1, 0, v, st())
+        if rc != 0 and v >= 0:
+            continue
+        assert rc == 0, _hip.last_error()
+        ref = F.linear(a, w, b) + res
+        assert (out.cpu().view(M, N) - ref).abs().max().item() < 2e-4, v
+    out = torch.empty(M * N, device=DEV)
+    _hip.check(lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), K, bd.data_ptr(), None, 0, None, 0,
+                                  out.data_ptr(), N, 1, 1, M, N, 1, _hip.CONV_SILU_OUT, -1, st()))
+    assert (out.cpu().view(M, N) - F.silu(F.linear(a, w, b))).abs().max().item() < 2e-4
+
+
+def test_conv_direct_stride2():
+    B, C, N, H, W = 2, 32, 48, 16, 16
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 3, 3, seed=2, scale=0.05), rnd(N, seed=3)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    xd, (wd, ldw), bd = nhwc(x), pack_w(w), b.to(DEV)
+    out = torch.empty(B * 8 * 8 * N, device=DEV)
+    _hip.check(lib().nd_conv_direct_nhwc(xd.data_ptr(), C, C, wd.data_ptr(), ldw, bd.data_ptr(), out.data_ptr(), N, B, H,
+                                         W, N, 3, 2, 1, st()))
+    assert (from_nhwc(out, B, 8, 8, N) - ref).abs().max().item() < 1e-4
+
+
+GN_CASES = [(2, 32, 0, 16, 16), (3, 192, 0, 8, 8), (2, 64, 32, 7, 7), (1, 768, 768, 8, 8), (2, 96, 0, 28, 28)]
+
+
+@pytest.mark.parametrize('B,C0,C1,H,W', GN_CASES)
+@pytest.mark.parametrize('mode', ['silu', 'plain', 'adagn', 'addvec', 'pool'])
+def test_groupnorm(B, C0, C1, H, W, mode):
+    if mode == 'pool' and (H % 2 or W % 2):
+        pytest.skip('odd size')
+    C = C0 + C1
+    xa = rnd(B, C0, H, W, seed=1) * 2 + 0.5
+    xb = rnd(B, C1, H, W, seed=2) if C1 else None
+    x = torch.cat([xa, xb], 1) if C1 else xa
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    scale, shift, add = 0.3 * rnd(B, C, seed=5), 0.3 * rnd(B, C, seed=6), rnd(B, C, seed=7)
+    xin = x + add[:, :, None, None] if mode == 'addvec' else x
+    ref = F.group_norm(xin, 32, gamma, beta, 1e-5)
+    if mode == 'adagn':
+        ref = ref * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    if mode != 'plain':
+        ref = F.silu(ref)
+    if mode == 'pool':
+        ref = F.avg_pool2d(ref, 2, 2)
+    xad = nhwc(xa)
+    xbd = nhwc(xb) if C1 else None
+    stats = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+    addd = add.to(DEV) if mode == 'addvec' else None
+    p = lambda t: None if t is None else t.data_ptr()
+    _hip.check(lib().nd_groupnorm_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(), B,
+                                             H * W, 32, st()))
+    sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
+    Ho, Wo = (H // 2, W // 2) if mode == 'pool' else (H, W)
+    out = torch.empty(B * Ho * Wo * C, device=DEV)
+    flags = (0 if mode == 'plain' else _hip.GN_SILU) | (_hip.GN_POOL2 if mode == 'pool' else 0)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(),
+                                             gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C, out.data_ptr(), C, B, H, W, 32,
+                                             1e-5, flags, st()))
+    # statistics themselves (float64 sums)
+    s = stats.cpu().view(B, 32, 2)
+    xg = xin.double().view(B, 32, -1)
+    assert torch.allclose(s[..., 0], xg.sum(-1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(s[..., 1], (xg * xg).sum(-1), rtol=1e-12, atol=1e-9)
+    assert (from_nhwc(out, B, Ho, Wo, C) - ref).abs().max().item() < 2e-5
+
+
+ATTN_CASES = [  # B, T, heads, hd, split_first
+    (2, 64, 2, 32, True), (1, 1024, 6, 64, True), (2, 256, 3, 64, False), (3, 196, 2, 32, True), (2, 49, 4, 64, True),
+    (1, 64, 2, 16, False), (1, 256, 2, 128, True), (1, 64, 1, 192, True), (1, 128, 1, 256, True),
+]
+
+
+@pytest.mark.parametrize('B,T,nh,hd,split', ATTN_CASES)
+def test_attention(B, T, nh, hd, split):
+    C = nh * hd
+    qkv = rnd(B, T, 3 * C, seed=1)
+    qkv[0, T // 2, :] *= 4.0            # a spiky token: exercises the online-softmax rescale
+    if split:
+        q, k, v = qkv.view(B, T, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        offs = (0, C, 2 * C, hd)
+    else:
+        q, k, v = qkv.view(B, T, nh, 3, hd).permute(3, 0, 2, 1, 4)
+        offs = (0, hd, 2 * hd, 3 * hd)
+    scale = hd ** -0.5
+    w = torch.softmax((q @ k.transpose(2, 3)) * scale, dim=-1)
+    ref = (w @ v).transpose(1, 2).reshape(B, T, C)
+    qd = qkv.contiguous().to(DEV)
+    out = torch.full((B * T * C,), float('nan'), device=DEV)
+    _hip.check(lib().nd_attention_nhwc(qd.data_ptr(), 3 * C, out.data_ptr(), C, B, T, nh, hd, offs[0], offs[1], offs[2],
+                                       offs[3], scale, st()))
+    got = out.cpu().view(B, T, C)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_timestep_embed_and_class_embedding(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, 'timestep_embedding.npz'))
+    t = torch.from_numpy(g['t']).to(DEV)
+    from nicediffusion.model import timestep_embedding
+    for dim, key in ((192, 'e192'), (64, 'e64'), (33, 'e33')):
+        got = timestep_embedding(t, dim).cpu().numpy()
+        assert np.abs(got - g[key]).max() < 2e-6, dim
+    B, D, R = 3, 128, 10
+    emb, tab = rnd(B, D, seed=1), rnd(R, D, seed=2)
+    y = torch.tensor([9, 0, 4])
+    ed, td, yd = emb.clone().to(DEV), tab.to(DEV), y.to(DEV)
+    sil = torch.empty(B * D, device=DEV)
+    _hip.check(lib().nd_embedding_add_silu(ed.data_ptr(), td.data_ptr(), yd.data_ptr(), R, B, D, sil.data_ptr(), st()))
+    ref = emb + tab[y]
+    assert (ed.cpu() - ref).abs().max().item() == 0
+    assert (sil.cpu().view(B, D) - F.silu(ref)).abs().max().item() < 1e-6
+
+
+def test_resample_and_layout():
+    B, C, H, W = 2, 32, 6, 10
+    x = rnd(B, C, H, W, seed=1)
+    xd = nhwc(x)
+    up = torch.empty(B * 4 * H * W * C, device=DEV)
+    _hip.check(lib().nd_upsample2x_nhwc(xd.data_ptr(), C, up.data_ptr(), C, B, H, W, C, st()))
+    assert torch.equal(from_nhwc(up, B, 2 * H, 2 * W, C), F.interpolate(x, scale_factor=2.0, mode='nearest'))
+    dn = torch.empty(B * (H // 2) * (W // 2) * C, device=DEV)
+    _hip.check(lib().nd_avgpool2x_nhwc(xd.data_ptr(), C, dn.data_ptr(), C, B, H, W, C, st()))
+    assert (from_nhwc(dn, B, H // 2, W // 2, C) - F.avg_pool2d(x, 2, 2)).abs().max().item() < 1e-6
+    # NCHW <-> NHWC with channel padding
+    x3 = rnd(B, 3, H, W, seed=2).to(DEV)
+    p = torch.full((B * H * W * 4,), float('nan'), device=DEV)
+    _hip.check(lib().nd_nchw_to_nhwc(x3.data_ptr(), p.data_ptr(), B, 3, H * W, 4, st()))
+    pv = p.view(B, H, W, 4)
+    assert torch.equal(pv[..., :3].permute(0, 3, 1, 2), x3) and not pv[..., 3].any()
+    back = torch.empty_like(x3)
+    _hip.check(lib().nd_nhwc_to_nchw(p.data_ptr(), back.data_ptr(), B, 3, H * W, 4, st()))
+    assert torch.equal(back, x3)
+
+
+def test_to_uint8():
+    x = torch.tensor([-1.5, -1.0, -0.999, 0.0, 0.5, 0.9999, 1.0, 2.0] * 3).view(1, 3, 8, 1)   # [B,C,H,W]
+    xd = nhwc(x)
+    out = torch.empty(8 * 3, dtype=torch.uint8, device=DEV)
+    _hip.check(lib().nd_to_uint8_hwc(xd.data_ptr(), 3, out.data_ptr(), 1, 8, 3, 0, st()))
+    ref = ((x + 1) * 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).reshape(-1)
+    assert torch.equal(out.cpu(), ref)
+    _hip.check(lib().nd_to_uint8_hwc(xd.data_ptr(), 3, out.data_ptr(), 1, 8, 3, 1, st()))
+    ref = (255 - ((x + 1) * 127.5).clamp(0, 255)).to(torch.uint8).permute(0, 2, 3, 1).reshape(-1)
+    assert torch.equal(out.cpu(), ref)
+
+
+def _coef_row(vals):
+    return torch.tensor([vals], dtype=torch.float32)
+
+
+@pytest.mark.parametrize('kind', ['ddim0', 'ddim_eta', 'ddpm_li', 'ddpm_learned', 'ddpm_fixed', 'ddim_cfg'])
+def test_sampler_step_kernels(kind):
+    """One step of each update rule vs the oracle's fp32 statement of diffusion.py:242-367."""
+    from oracle import diffusion_oracle as DO
+    B, C, R, S = 2, 3, 8, 10
+    sch = DO.Schedule(1000, S, 'cosine')
+    x, eps6, noise = rnd(B, C, R, R, seed=1), rnd(B, 2 * C, R, R, seed=2, scale=0.5), rnd(B, C, R, R, seed=3)
+    eps6u = rnd(B, 2 * C, R, R, seed=4, scale=0.5)
+    from nicediffusion.diffusion import Diffusion
+    from nicediffusion.model import DiffusionModel
+    m = DiffusionModel(resolution=8, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1,
+                       attention_resolutions=(), channel_mult=(1,), num_classes=4)
+    var = {'ddpm_learned': 'learned', 'ddpm_fixed': 'large'}.get(kind, 'learned_interpolation')
+    ddim = kind.startswith('ddim')
+    eta = 0.7 if kind == 'ddim_eta' else 0.0
+    cfg = kind == 'ddim_cfg'
+    d = Diffusion(m, 1000, S, var, 'simple', beta_schedule='cosine', use_ddim=ddim, ddim_eta=eta if ddim else None,
+                  guidance_method='classifier_free' if cfg else None, guidance_strength=0.8 if cfg else None,
+                  device=torch.device('cpu'))
+    coef = d.coefficient_table().to(DEV)
+    for t in (S - 1, 3, 0):
+        calls = {'n': 0}
+
+        def fake_model(xx, tt, yy):
+            calls['n'] += 1
+            return eps6 if calls['n'] == 1 else eps6u
+        so = DO.SamplerOracle(fake_model, sch, var, use_ddim=ddim, ddim_eta=eta,
+                              guidance_method='classifier_free' if cfg else None, guidance_strength=0.8 if cfg else None)
+        ref, _ = (so.ddim_step if ddim else so.ddpm_step)(x, t, torch.zeros(B, dtype=torch.long), noise)
+        xd = torch.zeros(B * R * R * 4, device=DEV)
+        _hip.check(lib().nd_nchw_to_nhwc(x.to(DEV).data_ptr(), xd.data_ptr(), B, C, R * R, 4, st()))
+        nd_ = torch.zeros(B * R * R * 4, device=DEV)
+        _hip.check(lib().nd_nchw_to_nhwc(noise.to(DEV).data_ptr(), nd_.data_ptr(), B, C, R * R, 4, st()))
+        ed = torch.zeros(B * R * R * 8, device=DEV)
+        _hip.check(lib().nd_nchw_to_nhwc(eps6.to(DEV).data_ptr(), ed.data_ptr(), B, 2 * C, R * R, 8, st()))
+        eud = torch.zeros(B * R * R * 8, device=DEV)
+        _hip.check(lib().nd_nchw_to_nhwc(eps6u.to(DEV).data_ptr(), eud.data_ptr(), B, 2 * C, R * R, 8, st()))
+        step = torch.tensor([t], dtype=torch.int32, device=DEV)
+        out = torch.zeros_like(xd)
+        eu = eud.data_ptr() if cfg else None
+        if ddim:
+            rc = lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+                                    step.data_ptr(), eta, nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4, 0, B,
+                                    R * R, C, st())
+        else:
+            rc = lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+                                    step.data_ptr(), d._var_kind(), nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4,
+                                    0, B, R * R, C, st())
+        _hip.check(rc)
+        got = torch.empty(B, C, R, R, device=DEV)
+        _hip.check(lib().nd_nhwc_to_nchw(out.data_ptr(), got.data_ptr(), B, C, R * R, 4, st()))
+        assert (got.cpu() - ref).abs().max().item() < 5e-6, (kind, t)
+    # step bookkeeping kernels
+    tm = torch.tensor([5, 15, 25], device=DEV)
+    stp = torch.tensor([2], dtype=torch.int32, device=DEV)
+    tout = torch.zeros(4, dtype=torch.int64, device=DEV)
+    _hip.check(lib().nd_fill_timestep(tm.data_ptr(), stp.data_ptr(), tout.data_ptr(), 4, st()))
+    _hip.check(lib().nd_step_advance(stp.data_ptr(), -1, st()))
+    assert tout.tolist() == [25] * 4 and stp.item() == 1
+
+
+def test_philox_noise_is_standard_normal():
+    """In-kernel noise (no injected tensor): DDPM step with x=0, eps=0 gives mean 0 and x_out = sigma * n."""
+    B, C, R = 8, 3, 64
+    n = B * R * R * 4
+    x = torch.zeros(n, device=DEV)
+    eps = torch.zeros(B * R * R * 8, device=DEV)
+    coef = torch.zeros(4, 8, device=DEV)
+    coef[:, 0] = 1.0        # log_var = 0 -> sigma = 1
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    outs = []
+    for seed in (1, 2):
+        out = torch.zeros(n, device=DEV)
+        _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
+                                      step.data_ptr(), _hip.VAR_FIXED, None, 0, seed, B, R * R, C, st()))
+        outs.append(out.view(-1, 4)[:, :3].cpu())
+    z = outs[0].flatten()
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1) < 0.01
+    assert abs((z ** 4).mean().item() - 3) < 0.1 and z.abs().max().item() < 7
+    assert not torch.equal(outs[0], outs[1])
+    assert abs(torch.corrcoef(torch.stack([outs[0].flatten(), outs[1].flatten()]))[0, 1].item()) < 0.01
+
+
+def test_qsample():
+    x0, nz = rnd(2, 3, 8, 8, seed=1).to(DEV), rnd(2, 3, 8, 8, seed=2).to(DEV)
+    out = torch.empty_like(x0)
+    _hip.check(lib().nd_qsample(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), x0.numel(), 0.6, 0.8, st()))
+    assert (out - (0.6 * x0 + 0.8 * nz)).abs().max().item() < 1e-6

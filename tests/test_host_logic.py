@@ -1,0 +1,231 @@
+"""Host-side logic of the product package (runs without a GPU): schedules, CLI glue, state_dict contract,
+default-init parity, C-ABI symbol table, fail-loud behaviour on CPU tensors."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from nicediffusion import _hip
+from nicediffusion import default_args as DA
+from nicediffusion.diffusion import Diffusion, get_beta_schedule, VarType
+from nicediffusion.model import DiffusionModel
+from nicediffusion.utils import make_argparser, get_dicts_from_args, convert_state_dict
+from nicediffusion.parallel import shard_slice
+from tests.cases import TINY_CFGS, SCHEDULE_CASES, CLI_CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = torch.device('cpu')
+
+
+def tiny_model():
+    return DiffusionModel(resolution=8, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                          attention_resolutions=(), channel_mult=(1,))
+
+
+@pytest.mark.parametrize('name', sorted(SCHEDULE_CASES))
+def test_product_schedule_tables_bit_exact(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, 'schedules.npz'))
+    T, S, sched = SCHEDULE_CASES[name]
+    d = Diffusion(tiny_model(), T, S, 'small', 'simple', beta_schedule=sched, device=CPU)
+    for attr in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod',
+                 'sqrt_one_minus_alphas_cumprod', 'sqrt_reciprocal_alphas_cumprod',
+                 'sqrt_reciprocal_alphas_minus_one_cumprod', 'posterior_mean_coef_x0', 'posterior_mean_coef_xt',
+                 'posterior_variance', 'log_posterior_var_clipped'):
+        assert np.array_equal(getattr(d, attr), g['{}/{}'.format(name, attr)]), (name, attr)
+    assert np.array_equal(d.timestep_map.numpy(), g['{}/timestep_map'.format(name)])
+    assert d.timestep_map.dtype == torch.long
+
+
+def test_coefficient_table_columns():
+    d = Diffusion(tiny_model(), 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True,
+                  ddim_eta=0.0, device=CPU)
+    tab = d.coefficient_table()
+    assert tab.shape == (250, 8) and tab.dtype == torch.float32
+    assert np.array_equal(tab[:, 0].numpy(), d.sqrt_reciprocal_alphas_cumprod.astype(np.float32))
+    assert np.array_equal(tab[:, 3].numpy(), d.alphas_cumprod_prev.astype(np.float32))
+    assert np.array_equal(tab[:, 6].numpy(), d.log_posterior_var_clipped.astype(np.float32))
+    assert np.array_equal(tab[:, 7].numpy(), np.log(d.betas).astype(np.float32))
+    d = Diffusion(tiny_model(), 1000, 50, 'large', 'simple', device=CPU)
+    assert np.array_equal(d.coefficient_table()[:, 6].numpy(),
+                          np.log(np.append(d.posterior_variance[1], d.betas[1:])).astype(np.float32))
+    d = Diffusion(tiny_model(), 1000, 50, 'small', 'simple', device=CPU)
+    assert np.array_equal(d.coefficient_table()[:, 6].numpy(),
+                          np.log(np.maximum(d.posterior_variance, 1e-20)).astype(np.float32))
+
+
+def test_constructor_errors():
+    m = tiny_model()
+    with pytest.raises(NotImplementedError):
+        Diffusion(m, 1000, 10, 'small', 'simple', guidance_method='bogus', device=CPU)
+    with pytest.raises(AssertionError):
+        Diffusion(m, 1000, 10, 'small', 'simple', guidance_method='classifier_free', guidance_strength=1.0, device=CPU)
+    with pytest.raises(AssertionError):
+        Diffusion(m, 1000, 10, 'small', 'simple', use_ddim=True, device=CPU)
+    with pytest.raises(NotImplementedError):
+        Diffusion(m, 1000, 10, 'tiny', 'simple', device=CPU)
+    with pytest.raises(NotImplementedError):
+        Diffusion(m, 1000, 10, 'small', 'L7', device=CPU)
+    with pytest.raises(NotImplementedError):
+        get_beta_schedule('quadratic', 10, 1e-4, 2e-2)
+    with pytest.raises(AssertionError):
+        Diffusion(m, 1000, 10, 'small', 'simple', betas=[0.1] * 5, device=CPU)
+    assert VarType.get_var_type('learned') is VarType.LEARNED
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must fail loudly, never silently run somewhere else."""
+    m = tiny_model()
+    with pytest.raises(_hip.NdHipError):
+        m(torch.zeros(1, 1, 8, 8), torch.zeros(1, dtype=torch.long))
+    d = Diffusion(m, 1000, 10, 'small', 'simple', device=CPU)
+    with pytest.raises(_hip.NdHipError):
+        d.denoise(x=torch.zeros(1, 1, 8, 8), batch_size=1, progress=False)
+    with pytest.raises(AssertionError):      # label iff conditional (diffusion.py:179)
+        d.denoise(x=torch.zeros(1, 1, 8, 8), kwargs={'y': torch.zeros(1, dtype=torch.long)}, batch_size=1)
+    with pytest.raises(AssertionError):      # model.py:452-454
+        m(torch.zeros(1, 1, 8, 8), torch.zeros(1, dtype=torch.long), y=torch.zeros(1, dtype=torch.long))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'nice-diffusion_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+# ------------------------------------------------------------------------------------------------- CLI (A12)
+@pytest.mark.parametrize('name', sorted(CLI_CASES))
+def test_cli_dicts_match_reference(golden_dir, name):
+    ref = json.load(open(os.path.join(golden_dir, 'cli_dicts.json')))[name]
+    args = make_argparser('diff_sample').parse_args(CLI_CASES[name])
+    other, margs, dargs = get_dicts_from_args(args)
+
+    def norm(d):
+        return json.loads(json.dumps(d, default=lambda o: list(o)))
+    assert norm(margs) == ref['model']
+    assert norm(dargs) == ref['diff']
+    assert norm(other) == ref['other']
+
+
+def test_cli_errors():
+    p = make_argparser('diff_sample')
+    with pytest.raises(NotImplementedError):
+        get_dicts_from_args(p.parse_args(['--model_path', 'foo.pt', '--batch_size', '1', '--num_samples', '1']))
+    with pytest.raises(Exception):
+        get_dicts_from_args(p.parse_args(['--model_path', 'foo.pt', '-c', '--batch_size', '1', '--num_samples', '1']))
+    with pytest.raises(NotImplementedError):
+        make_argparser('nope')
+    make_argparser('diff_train')
+
+
+def test_presets_values():
+    assert DA.OPENAI_64_MODEL_ARGS == {'resolution': 64, 'attention_resolutions': (8, 16, 32),
+                                      'channel_mult': (1, 2, 3, 4), 'num_head_channels': 64, 'in_channels': 3,
+                                      'out_channels': 6, 'model_channels': 192, 'num_res_blocks': 3,
+                                      'split_qkv_first': True, 'dropout': 0.05, 'resblock_updown': True,
+                                      'use_adaptive_gn': True, 'num_classes': 1000}
+    assert DA.EMNIST_DIFFUSION_ARGS['guidance_method'] == 'classifier_free'
+    assert DA.OPENAI_128_MODEL_ARGS['num_heads'] == 4 and DA.OPENAI_256_MODEL_ARGS['channel_mult'] == (1, 1, 2, 2, 4, 4)
+
+
+# ------------------------------------------------------------------------------------------------- state_dict (A10)
+@pytest.mark.parametrize('pname,margs', [('EMNIST', DA.EMNIST_MODEL_ARGS), ('OPENAI_64', DA.OPENAI_64_MODEL_ARGS)])
+def test_state_dict_contract(golden_dir, pname, margs):
+    meta = json.load(open(os.path.join(golden_dir, 'preset_state_dicts.json')))[pname]
+    with torch.device('meta'):
+        m = DiffusionModel(**margs)
+    sd = m.state_dict()
+    assert list(sd.keys()) == meta['keys']
+    assert [list(v.shape) for v in sd.values()] == meta['shapes']
+    assert m.conditional and m.in_channels == margs['in_channels'] and m.resolution == margs['resolution']
+    assert m.num_classes == margs['num_classes'] and m.model_channels == margs['model_channels']
+
+
+@pytest.mark.parametrize('name', sorted(TINY_CFGS))
+def test_tiny_state_dict_loads_strict(name):
+    from oracle import unet_oracle as UO      # tests may use the oracle's key table
+    cfg = TINY_CFGS[name]
+    m = DiffusionModel(**cfg)
+    m.load_state_dict(UO.synth_state_dict(cfg), strict=True)
+
+
+def test_default_init_matches_reference_rng_stream(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'init_seed0.npz'))
+    torch.manual_seed(0)
+    m = DiffusionModel(**TINY_CFGS['adagn_updown'])
+    sd = m.state_dict()
+    for k in g.files:
+        assert np.array_equal(sd[k].numpy(), g[k]), k
+    # the zero-initialised tensors of model.py:177,253,448
+    assert not sd['downsampling.1.0.out_conv.weight'].any() and not sd['out.2.weight'].any()
+    assert not sd['middle_block.1.proj_out.weight'].any()
+
+
+def test_convert_state_dict_names():
+    sd = {'input_blocks.1.0.in_layers.0.weight': 1, 'output_blocks.2.1.qkv.bias': 2, 'time_embed.0.weight': 3,
+          'label_emb.weight': 4, 'middle_block.0.emb_layers.1.bias': 5, 'input_blocks.4.0.out_layers.3.weight': 6,
+          'output_blocks.0.0.skip_connection.weight': 7, 'out.2.bias': 8, 'input_blocks.1.0.out_layers.0.bias': 9,
+          'input_blocks.1.0.in_layers.2.bias': 10}
+    out = convert_state_dict(dict(sd))
+    assert list(out.keys()) == ['downsampling.1.0.in_norm.weight', 'upsampling.2.1.qkv_nin.bias', 'step_embed.0.weight',
+                                'class_embedding.weight', 'middle_block.0.step_embedding.bias',
+                                'downsampling.4.0.out_conv.weight', 'upsampling.0.0.skip.weight', 'out.2.bias',
+                                'downsampling.1.0.out_norm.bias', 'downsampling.1.0.in_conv.bias']
+    assert list(out.values()) == list(sd.values())
+
+
+# ------------------------------------------------------------------------------------------------- sharding
+def test_shard_slice_partitions():
+    for n in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            rows = []
+            for r in range(world):
+                s = shard_slice(n, r, world)
+                rows.extend(range(s.start, s.stop))
+            assert rows == list(range(n))
+    assert shard_slice(512, 3, 8) == slice(192, 256)
+    with pytest.raises(ValueError):
+        shard_slice(8, 8, 8)
+
+
+# ------------------------------------------------------------------------------------------------- C ABI
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'nd_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(nd_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_header_symbol():
+    names = _header_functions()
+    assert len(names) >= 20
+    assert sorted(_hip.EXPORTS) == names, 'ctypes table out of sync with include/nd_hip.h'
+    path = _hip.lib_path()
+    assert os.path.exists(path), 'libnd_hip.so not built (run __graft_entry__.build())'
+    lib = _hip.load()                                   # loads without a GPU; no compute calls here
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.nd_version() >= 100
+    assert lib.nd_conv_num_variants() >= 4
+    out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (nd_[a-z0-9_]+)', out))
+    assert exported == set(names)
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch."""
+    lib = _hip.load()
+    rc = lib.nd_conv_nhwc(None, 32, 32, None, 0, 0, None, 32, None, None, 0, None, 0, None, 32, 1, 8, 8, 32, 3, 0, -1,
+                          None)
+    assert rc == -1 and 'null' in _hip.last_error()
+    rc = lib.nd_attention_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)
+    assert rc == -1 and 'multiple of 8' in _hip.last_error()
+    rc = lib.nd_groupnorm_stats_nhwc(16, 30, 32, None, 0, 0, None, 0, 16, 1, 4, 32, None)
+    assert rc == -1
