@@ -76,6 +76,10 @@ int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int
 
 /* Number of tile-shape variants nd_conv_nhwc accepts for `variant` (0 .. n-1). */
 int nd_conv_num_variants(void);
+/* The variant nd_conv_nhwc picks for a shape when `variant` < 0 (host-only query; < 0 on error), and a variant's
+ * block tile (pixels x output channels) and thread count.  Used by bench.py to attribute launches to kernels. */
+int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias);
+int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);
 
 /* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
  * (Downsample with_conv, model.py:103-105).  w layout as above.  out is [NI, Ho, Wo, N]. */

@@ -387,6 +387,47 @@ static bool plan_tiles(int bm, int nt, int taps, int NI, int H, int W, TilePlan*
 
 }  // namespace nd
 
+
+// Choose the tile-shape variant (and its spatial tiling) for a problem: minimise
+//   ceil(blocks / slots) * tile cost,   slots = CUs x blocks/CU that fit LDS and the wave budget.
+static int select_variant(int variant, int taps, int pNI, int pH, int pW, int N, nd::TilePlan* out_tp) {
+    using namespace nd;
+    int best_v = -1;
+    TilePlan best_tp{};
+    double best_cost = 0;
+    for (int v = 0; v < kNumVariants; ++v) {
+        if (variant >= 0 && v != variant) continue;
+        const Variant& V = kVariants[v];
+        TilePlan tp;
+        if (!plan_tiles(V.bm(), V.nt(), taps, pNI, pH, pW, &tp)) continue;
+        const long nblk_n = (N + V.bn() - 1) / V.bn();
+        const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
+        const size_t lds = (size_t)(2 * tp.hp + 2 * V.bn()) * 128;
+        if (lds > 160 * 1024) continue;
+        int per_cu = (int)(160 * 1024 / lds);
+        const int wave_cap = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;   // keep <= 2 waves / SIMD
+        if (per_cu > wave_cap) per_cu = wave_cap;
+        if (per_cu < 1) per_cu = 1;
+        const long slots = 256L * per_cu;
+        const long rounds = (nblocks + slots - 1) / slots;
+        // cost of one round: a CU runs per_cu blocks concurrently sharing its 4 matrix pipes
+        double cost = (double)rounds * per_cu * V.bm() * V.bn();
+        // small wave tiles re-read operands from LDS more often and have less MFMA back-to-back: mild penalty
+        const double eff = (V.tm * V.tn >= 4) ? 1.0 : (V.tm * V.tn >= 2 ? 0.93 : 0.85);
+        cost /= eff;
+        if (best_v < 0 || cost < best_cost * 0.999) {
+            best_v = v; best_tp = tp; best_cost = cost;
+        }
+    }
+    if (best_v >= 0) *out_tp = best_tp;
+    return best_v;
+}
+
+// flat pixel list for 1x1 (keeps tiles dense for odd image sizes)
+static bool use_flat(int taps, int flags, const float* rowbias) {
+    return taps == 1 && !(flags & (ND_CONV_IN_UP2X | ND_CONV_RES_UP2X)) && rowbias == nullptr;
+}
+
 using namespace nd;
 
 extern "C" int nd_conv_num_variants(void) { return kNumVariants; }
@@ -419,37 +460,11 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const long M = (long)NI * H * W;
     // 1x1: the spatial structure is irrelevant -> flat pixel list (keeps tiles dense for odd image sizes)
     int pNI = NI, pH = H, pW = W;
-    const bool flat = (taps == 1) && !up && !res_up && !rowbias;
+    const bool flat = use_flat(taps, flags, rowbias);
     if (flat) { pNI = 1; pH = 1; pW = (int)M; }
 
-    // ---- choose the variant: minimise  ceil(blocks / slots) * tile cost  (slots = CUs x blocks/CU that fit LDS)
-    int best_v = -1;
     TilePlan best_tp{};
-    double best_cost = 0;
-    for (int v = 0; v < kNumVariants; ++v) {
-        if (variant >= 0 && v != variant) continue;
-        const Variant& V = kVariants[v];
-        TilePlan tp;
-        if (!plan_tiles(V.bm(), V.nt(), taps, pNI, pH, pW, &tp)) continue;
-        const long nblk_n = (N + V.bn() - 1) / V.bn();
-        const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = (size_t)(2 * tp.hp + 2 * V.bn()) * 128;
-        if (lds > 160 * 1024) continue;
-        int per_cu = (int)(160 * 1024 / lds);
-        const int wave_cap = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;   // keep <= 2 waves / SIMD
-        if (per_cu > wave_cap) per_cu = wave_cap;
-        if (per_cu < 1) per_cu = 1;
-        const long slots = 256L * per_cu;
-        const long rounds = (nblocks + slots - 1) / slots;
-        // cost of one round: a CU runs per_cu blocks concurrently sharing its 4 matrix pipes
-        double cost = (double)rounds * per_cu * V.bm() * V.bn();
-        // small wave tiles re-read operands from LDS more often and have less MFMA back-to-back: mild penalty
-        const double eff = (V.tm * V.tn >= 4) ? 1.0 : (V.tm * V.tn >= 2 ? 0.93 : 0.85);
-        cost /= eff;
-        if (best_v < 0 || cost < best_cost * 0.999) {
-            best_v = v; best_tp = tp; best_cost = cost;
-        }
-    }
+    const int best_v = select_variant(variant, taps, pNI, pH, pW, N, &best_tp);
     if (best_v < 0) return fail_arg(fn, "no tile variant fits this shape");
 
     const Variant& V = kVariants[best_v];
@@ -469,4 +484,24 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const size_t lds = (size_t)(2 * best_tp.hp + 2 * V.bn()) * 128;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
+}
+
+extern "C" int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias) {
+    if (!(ksize == 1 || ksize == 3) || NI <= 0 || H <= 0 || W <= 0 || N <= 0) return ND_E_ARG;
+    const int taps = ksize * ksize;
+    int pNI = NI, pH = H, pW = W;
+    if (use_flat(taps, flags, has_rowbias ? reinterpret_cast<const float*>(1) : nullptr)) {
+        pNI = 1; pH = 1; pW = NI * H * W;
+    }
+    TilePlan tp{};
+    const int v = select_variant(-1, taps, pNI, pH, pW, N, &tp);
+    return v < 0 ? ND_E_ARG : v;
+}
+
+extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads) {
+    if (variant < 0 || variant >= kNumVariants) return ND_E_ARG;
+    if (bm) *bm = kVariants[variant].bm();
+    if (bn) *bn = kVariants[variant].bn();
+    if (threads) *threads = kVariants[variant].nt();
+    return ND_OK;
 }

@@ -14,7 +14,8 @@ __global__ void timestep_embed_kernel(const int64_t* t, const float* freqs, int 
     float v = 0.f;   // zero pad for odd dims
     if (i < 2 * half) {
         const int k = (i < half) ? i : i - half;
-        const float arg = (float)t[b] * freqs[k];
+        // rounded fp32 product (the reference materialises t*f before cos/sin); no FMA contraction into the range reduction
+        const float arg = __fmul_rn((float)t[b], freqs[k]);
         v = (i < half) ? cosf(arg) : sinf(arg);
     }
     out[(size_t)b * ld + i] = v;

@@ -8,6 +8,9 @@
 // Arithmetic follows the reference's fp32 operation order so teacher-forced steps agree to rounding.
 #include "nd_common.h"
 
+// keep the reference's one-rounding-per-op fp32 arithmetic (no mul+add contraction) in this file
+#pragma clang fp contract(off)
+
 namespace nd {
 
 // ---- Philox4x32-10 + Box-Muller: counter-based N(0,1), no state in memory --------------------------------------

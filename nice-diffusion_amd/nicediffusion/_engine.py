@@ -40,6 +40,7 @@ class _Pool:
     def __init__(self, device):
         self.device = device
         self.free = []      # list of (numel, tensor)
+        self.all = []       # every buffer ever handed out: the plan keeps them alive (launches hold raw pointers)
         self.total = 0
 
     def take(self, numel):
@@ -50,6 +51,7 @@ class _Pool:
         if best is not None and self.free[best][0] <= 2 * numel:
             return self.free.pop(best)[1]
         t = torch.empty(numel, dtype=torch.float32, device=self.device)
+        self.all.append(t)
         self.total += numel
         return t
 
@@ -67,6 +69,7 @@ class UNetPlan:
         _hip.require_gfx950(dev.index if dev.index is not None else torch.cuda.current_device())
         self.device = dev
         self.ops = []           # (fn, args, label)
+        self.meta = []          # per launch: label, entry point, algorithmic flops, conv tile variant
         self.keep = []          # tensors that must outlive the plan (packed weights, etc.)
         self.pool = _Pool(dev)
         self.flops = 0          # algorithmic flops of the MFMA launches (2 per MAC)
@@ -89,8 +92,9 @@ class UNetPlan:
         self.weight_signature = model._weight_signature()
 
     # ------------------------------------------------------------------------------------------------ emit helpers
-    def _emit(self, fn, args, label):
+    def _emit(self, fn, args, label, flops=0, variant=None, ksize=None):
         self.ops.append((fn, tuple(args), label))
+        self.meta.append(dict(label=label, fn=fn.__name__, flops=flops, variant=variant, ksize=ksize))
 
     def _new(self, NI, H, W, C):
         return Act(self.pool.take(NI * H * W * C), NI, H, W, C)
@@ -127,8 +131,9 @@ class UNetPlan:
                 w_ptr, ldw, bias, rowbias, ld_rowbias,
                 None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                 out.ptr, out.ld, NI, H, W, N, ksize, flags, -1]
-        self._emit(self.lib.nd_conv_nhwc, args, label)
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
+        var = self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 0 if rowbias is None else 1)
+        self._emit(self.lib.nd_conv_nhwc, args, label, flops=fl, variant=var, ksize=ksize)
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         return out
@@ -138,7 +143,8 @@ class UNetPlan:
         assert w.is_contiguous() and K % 4 == 0
         args = [src_ptr, K, K, None, 0, 0, w.data_ptr(), K, None if bias is None else bias.detach().data_ptr(),
                 None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1]
-        self._emit(self.lib.nd_conv_nhwc, args, label)
+        var = self.lib.nd_conv_select_variant(1, 1, M, N, 1, flags, 0)
+        self._emit(self.lib.nd_conv_nhwc, args, label, flops=2 * M * N * K, variant=var, ksize=1)
         self.flops += 2 * M * N * K
 
     def groupnorm(self, src, norm, out=None, src2=None, scale_ptr=None, shift_ptr=None, ld_ss=0, silu=True,
@@ -205,7 +211,8 @@ class UNetPlan:
             self.e_all = torch.empty(NI * self.e_ld, **f32)
             args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self.e_w.data_ptr(), ed, self.e_b.data_ptr(),
                     None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1]
-            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all')
+            var = lib.nd_conv_select_variant(1, 1, NI, self.e_ld, 1, 0, 0)
+            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=var, ksize=1)
             self.flops += 2 * NI * self.e_ld * ed
 
         # ---- the UNet proper
@@ -238,6 +245,7 @@ class UNetPlan:
             bound.append((fn, args, label))
         self.ops = bound
         self.workspace_floats = self.pool.total
+        self.buffers = self.pool.all      # owned for the plan's lifetime
         self.pool = None
 
     def _run_block(self, block, x, skip, owned, skip_owned=False):
@@ -347,7 +355,8 @@ class UNetPlan:
         else:
             offs = (0, hd, 2 * hd, 3 * hd)
         self._emit(self.lib.nd_attention_nhwc, [qkv.ptr, qkv.ld, a.ptr, a.ld, NI, T, nh, hd, offs[0], offs[1], offs[2],
-                                                offs[3], float(ab.scale)], 'attention')
+                                                offs[3], float(ab.scale)], 'attention',
+                   flops=4 * NI * nh * T * T * hd)
         self.flops += 4 * NI * nh * T * T * hd
         self.conv_flops['attention'] = self.conv_flops.get('attention', 0) + 4 * NI * nh * T * T * hd
         self._release(qkv)
@@ -395,7 +404,8 @@ class UNetPlan:
                 raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
 
     def run_timed(self):
-        """Eager run with a HIP event pair around every launch; returns [(label, fn name, ms)] (for bench/profiles)."""
+        """Eager run with a HIP event pair around every launch (recorded on the launch stream); returns one dict per
+        launch: the plan's meta (label, entry point, flops, conv variant) plus ``ms``."""
         stream = self._stream()
         self.gn_stats.zero_()
         evs = []
@@ -407,6 +417,6 @@ class UNetPlan:
             b.record()
             if rc != 0:
                 raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
-            evs.append((label, fn.__name__, a, b))
+            evs.append((a, b))
         torch.cuda.synchronize()
-        return [(label, name, a.elapsed_time(b)) for label, name, a, b in evs]
+        return [dict(m, ms=a.elapsed_time(b)) for m, (a, b) in zip(self.meta, evs)]

@@ -52,6 +52,8 @@ SIGNATURES = {
 _SPECIAL = {
     'nd_version': ([], _i),
     'nd_conv_num_variants': ([], _i),
+    'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),
+    'nd_conv_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_last_error': ([], ctypes.c_char_p),
     'nd_device_arch': ([], ctypes.c_char_p),
 }

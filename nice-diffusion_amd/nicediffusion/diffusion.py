@@ -183,12 +183,14 @@ class Diffusion:
     # ---------------------------------------------------------------------------------------------- reverse process
     @torch.no_grad()
     def denoise(self, x=None, kwargs=None, start_step=None, steps_to_do=None, batch_size=1, ema_params=None,
-                progress=True, noise=None, trace=None):
+                progress=True, noise=None, trace=None, first_index=None):
         """Run the reverse chain and return x_0-ish samples [B, C, R, R] (reference diffusion.py:156-226).
 
         Extra keyword arguments (not in the reference): ``noise`` -- tensor [S, B, C, R, R] with the N(0,1) draw to
         use at each rescaled step (parity tests; default is in-kernel Philox noise); ``trace`` -- list that receives
-        x after every step (NCHW clones; disables graph replay).
+        x after every step (NCHW clones; disables graph replay); ``first_index`` -- rescaled index of the first
+        step to take (default ``steps_to_do - 1`` as in the reference, whose loop always ends at index 0); with it a
+        test can take one teacher-forced step at any index.
         """
         if kwargs is None:
             kwargs = {}
@@ -217,13 +219,13 @@ class Diffusion:
             x = x.to(self.device)
             _hip.require_device(x, 'x')
             y = kwargs.get('y')
-            return self._run_loop(x.float().contiguous(), y, steps_to_do, progress, noise, trace)
+            return self._run_loop(x.float().contiguous(), y, steps_to_do, progress, noise, trace, first_index)
         finally:
             if original is not None:
                 for name, p in model.named_parameters():
                     p.data = original[name]
 
-    def _run_loop(self, x, y, steps_to_do, progress, noise, trace):
+    def _run_loop(self, x, y, steps_to_do, progress, noise, trace, first_index=None):
         model = self.model
         lib = _hip.load()
         B = x.shape[0]
@@ -244,10 +246,12 @@ class Diffusion:
                       tmap=self.timestep_map.to(dev).contiguous(),
                       step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, graph_key=None, noise=None)
             self._loops = {key: st}
+        first = steps_to_do - 1 if first_index is None else int(first_index)
+        assert 0 <= first < len(self.betas) and first - steps_to_do + 1 >= 0, 'step index out of range'
         need_noise = (not self.use_ddim) or (self.ddim_eta != 0)
         noise_ptr, noise_stride = None, 0
         if noise is not None and need_noise:
-            assert noise.shape[0] >= steps_to_do and tuple(noise.shape[1:]) == (B, C, R, R), 'noise must be [S,B,C,R,R]'
+            assert noise.shape[0] > first and tuple(noise.shape[1:]) == (B, C, R, R), 'noise must be [S,B,C,R,R]'
             S = noise.shape[0]
             nb = st['noise']
             if nb is None or nb.numel() != S * B * HW * plan.Cin_p:
@@ -272,7 +276,7 @@ class Diffusion:
             plan.y_in[:B].copy_(y.to(torch.int64))
             if cfg:
                 plan.y_in[B:].zero_()              # null class = label 0 (diffusion.py:281,344)
-        st['step'].fill_(steps_to_do - 1)
+        st['step'].fill_(first)
 
         eps_ptr = plan.out.data_ptr()
         eps_u_ptr = plan.out.data_ptr() + 4 * B * HW * plan.Cout_p if cfg else None

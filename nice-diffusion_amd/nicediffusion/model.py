@@ -187,7 +187,9 @@ class DiffusionModel(nn.Module):
                     raise _hip.NdHipError('parameters must be fp32')
             with torch.no_grad():
                 plan = UNetPlan(self, batch)
-            self._plans = {batch: plan} if len(self._plans) >= 4 else dict(self._plans, **{batch: plan})
+            if len(self._plans) >= 4:
+                self._plans = {}
+            self._plans[batch] = plan
         return plan
 
     def _apply(self, fn, *a, **k):

@@ -213,7 +213,11 @@ def test_attention(B, T, nh, hd, split):
                                        offs[3], scale, st()))
     got = out.cpu().view(B, T, C)
     assert torch.isfinite(got).all()
-    assert (got - ref).abs().max().item() < 2e-5
+    # the spiked token drives |score| to ~1e2, where one fp32 ulp of the exponent is ~1e-5 relative in p
+    ref64 = (torch.softmax((q.double() @ k.double().transpose(2, 3)) * scale, dim=-1) @ v.double()).transpose(1, 2).reshape(B, T, C)
+    err_ref = (ref.double() - ref64).abs().max().item()
+    err = (got.double() - ref64).abs().max().item()
+    assert err < max(5 * err_ref, 2e-5), (err, err_ref)
 
 
 def test_timestep_embed_and_class_embedding(golden_dir):
@@ -223,7 +227,13 @@ def test_timestep_embed_and_class_embedding(golden_dir):
     from nicediffusion.model import timestep_embedding
     for dim, key in ((192, 'e192'), (64, 'e64'), (33, 'e33')):
         got = timestep_embedding(t, dim).cpu().numpy()
-        assert np.abs(got - g[key]).max() < 2e-6, dim
+        # exact given the same frequency table; but torch.exp on the CPU differs by 1 ulp between hosts (AVX2 vs
+        # AVX-512 paths), and 1 ulp of a frequency is ~3e-5 of phase at t ~ 1000: the reference moves by the same amount
+        assert np.abs(got - g[key]).max() < 1e-4, dim
+        f = torch.exp(torch.arange(dim // 2, dtype=torch.float32) * -(math.log(10000) / (dim // 2)))
+        arg = t.cpu()[:, None].float() * f[None]
+        same_host = torch.cat([torch.cos(arg), torch.sin(arg)], 1).numpy()
+        assert np.abs(got[:, :2 * (dim // 2)] - same_host).max() < 1e-6, dim
     B, D, R = 3, 128, 10
     emb, tab = rnd(B, D, seed=1), rnd(R, D, seed=2)
     y = torch.tensor([9, 0, 4])
@@ -292,12 +302,13 @@ def test_sampler_step_kernels(kind):
                   guidance_method='classifier_free' if cfg else None, guidance_strength=0.8 if cfg else None,
                   device=torch.device('cpu'))
     coef = d.coefficient_table().to(DEV)
+    nout = 2 * C if var in ('learned', 'learned_interpolation') else C
     for t in (S - 1, 3, 0):
         calls = {'n': 0}
 
         def fake_model(xx, tt, yy):
             calls['n'] += 1
-            return eps6 if calls['n'] == 1 else eps6u
+            return (eps6 if calls['n'] == 1 else eps6u)[:, :nout]
         so = DO.SamplerOracle(fake_model, sch, var, use_ddim=ddim, ddim_eta=eta,
                               guidance_method='classifier_free' if cfg else None, guidance_strength=0.8 if cfg else None)
         ref, _ = (so.ddim_step if ddim else so.ddpm_step)(x, t, torch.zeros(B, dtype=torch.long), noise)
