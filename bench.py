@@ -155,6 +155,7 @@ def main():
     ap.add_argument('--chain', type=int, default=PRESET_STEPS, help='(debug) DDIM steps per pass; the metric needs 250')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='(debug/profiling) launch every step eagerly instead of hipGraph replay')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -172,6 +173,8 @@ def main():
         dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
 
     margs, model, diff = build(device)
+    if args.no_graph:
+        diff.use_graph = False
     B = args.batch
     Bg = B * world
     # global batch generated identically on every rank, then sliced (an N-GPU run is comparable row by row)

@@ -15,6 +15,14 @@ from . import _hip
 GN_GROUPS = 32
 GN_EPS = 1e-5
 
+# (device index, NI, H, W, Cin, N, ksize, flags, has_rowbias, has_residual) -> fastest tile variant, measured once
+_TUNED = {}
+
+
+def _autotune_enabled():
+    import os
+    return os.environ.get('ND_AUTOTUNE', '1') != '0'
+
 
 def _pad4(n):
     return (n + 3) // 4 * 4
@@ -92,9 +100,9 @@ class UNetPlan:
         self.weight_signature = model._weight_signature()
 
     # ------------------------------------------------------------------------------------------------ emit helpers
-    def _emit(self, fn, args, label, flops=0, variant=None, ksize=None):
+    def _emit(self, fn, args, label, flops=0, variant=None, ksize=None, shape=None):
         self.ops.append((fn, tuple(args), label))
-        self.meta.append(dict(label=label, fn=fn.__name__, flops=flops, variant=variant, ksize=ksize))
+        self.meta.append(dict(label=label, fn=fn.__name__, flops=flops, variant=variant, ksize=ksize, shape=shape))
 
     def _new(self, NI, H, W, C):
         return Act(self.pool.take(NI * H * W * C), NI, H, W, C)
@@ -132,11 +140,43 @@ class UNetPlan:
                 None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                 out.ptr, out.ld, NI, H, W, N, ksize, flags, -1]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
-        var = self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 0 if rowbias is None else 1)
-        self._emit(self.lib.nd_conv_nhwc, args, label, flops=fl, variant=var, ksize=ksize)
+        var = self._pick_variant(args, (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None,
+                                        residual is not None), fl)
+        args[-1] = var
+        self._emit(self.lib.nd_conv_nhwc, args, label, flops=fl, variant=var, ksize=ksize,
+                   shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         return out
+
+    def _pick_variant(self, args, key, flops):
+        """Tile-shape variant for one conv launch: measured on the device (3 timed launches per candidate, best
+        kept, cached per shape) unless ND_AUTOTUNE=0, in which case the library's cost model decides."""
+        NI, H, W, C, N, ksize, flags, has_rb, _ = key
+        heur = self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0)
+        if not _autotune_enabled() or flops < 2e8:
+            return heur
+        ck = (self.device.index,) + key
+        if ck in _TUNED:
+            return _TUNED[ck]
+        stream = self._stream()
+        best, best_ms = heur, None
+        for v in range(self.lib.nd_conv_num_variants()):
+            a = list(args)
+            a[-1] = v
+            if self.lib.nd_conv_nhwc(*a, stream) != 0:
+                continue                              # this tile shape does not fit the problem
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                self.lib.nd_conv_nhwc(*a, stream)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if best_ms is None or ms < best_ms:
+                best, best_ms = v, ms
+        _TUNED[ck] = best
+        return best
 
     def linear(self, src_ptr, M, K, weight, bias, out_ptr, N, flags=0, label='linear'):
         w = weight.detach()

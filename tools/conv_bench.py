@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of nd_conv_nhwc on one shape (GPU box only):
+   python tools/conv_bench.py NI H W Cin N ksize [variant] [iters]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'nice-diffusion_amd'))
+import torch
+from nicediffusion import _hip
+a = sys.argv[1:]
+NI, H, W, C, N, ks = [int(v) for v in a[:6]]
+variants = [int(v) for v in a[6].split(',')] if len(a) > 6 else [-1]
+iters = int(a[7]) if len(a) > 7 else 20
+lib = _hip.load()
+dev = 'cuda'
+torch.manual_seed(0)
+x = torch.randn(NI * H * W * C, device=dev)
+w = torch.randn(ks * ks * N * C, device=dev) * 0.02
+b = torch.randn(N, device=dev)
+out = torch.empty(NI * H * W * N, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+fl = 2.0 * NI * H * W * N * ks * ks * C
+for v in variants:
+    def run():
+        rc = lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), C, b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
+                              NI, H, W, N, ks, 0, v, st)
+        assert rc == 0, _hip.last_error()
+    try:
+        run()
+    except AssertionError as e:
+        print('variant', v, 'n/a', e); continue
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print('shape', (NI, H, W, C, N, ks), 'variant', v, 'auto->%d' % lib.nd_conv_select_variant(NI, H, W, N, ks, 0, 0) if v < 0 else '',
+          '%.3f ms  %.1f TFLOP/s' % (ms, fl / ms / 1e9))
