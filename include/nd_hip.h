@@ -64,13 +64,13 @@ int nd_embedding_add_silu(float* emb, const float* table, const int64_t* y, int 
  *   ksize 3: nn.Conv2d 3x3 stride 1 pad 1 (model.py:173,177,367,448,72);  ksize 1: nn.Conv2d 1x1 / nn.Conv1d k=1 /
  *   nn.Linear (model.py:169,247,253,180,349-351) -- for those pass NI=1, H=1, W=M.
  *   The input is the channel concatenation of x0 (C0 channels, stride ldx0) and x1 (C1, ldx1) (torch.cat,
- *   model.py:474); x1 may be NULL with C1 = 0.  If C1 > 0, C0 must be a multiple of 32.
- *   w is [ksize*ksize][N][ldw] fp32 (tap-major, input channel contiguous; see nd_repack_conv_weight), ldw >= C0+C1.
+ *   model.py:474); x1 may be NULL with C1 = 0.
+ *   w is the weight tensor over the C0+C1 concatenated input channels in MFMA-fragment order (nd_repack_conv_weight).
  *   bias [N] | NULL;  rowbias [NI][ld_rowbias] | NULL (per-image bias: the timestep embedding of model.py:205);
  *   residual [NI,H,W,N] stride ldr | NULL (model.py:211, :291).  `variant` < 0 selects the tile shape automatically.
  */
 int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                 const float* w, int ldw, const float* bias, const float* rowbias, int ld_rowbias,
+                 const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                  const float* residual, int ldr, float* out, int ldo,
                  int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream);
 
@@ -82,13 +82,16 @@ int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, in
 int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);
 
 /* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
- * (Downsample with_conv, model.py:103-105).  w layout as above.  out is [NI, Ho, Wo, N]. */
-int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+ * (Downsample with_conv, model.py:103-105).  Weights in PyTorch's own OIHW layout.  out is [NI, Ho, Wo, N]. */
+int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, const float* bias,
                         float* out, int ldo, int NI, int H, int W, int N, int ksize, int stride, int pad,
                         nd_stream_t stream);
 
-/* OIHW [N][C][k][k] -> [k*k][N][ldw] (zero-filled for c >= C); run once at load_state_dict time. */
-int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, int ldw, nd_stream_t stream);
+/* Weight repack, run once at load time: OIHW [N][C][k][k] (k = 1 or 3; Conv1d [N][C][1] and Linear [N][C] are the
+ * k = 1 case) -> MFMA-fragment order [c32][n tile][tap][kc][lane][4], zero padded, so that every B operand of the
+ * matrix instruction is one coalesced 1 KiB load.  w_out must hold nd_conv_weight_floats(N, C, ksize) floats. */
+int64_t nd_conv_weight_floats(int N, int C, int ksize);
+int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, nd_stream_t stream);
 
 /* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1) ------------------------------------------
  * stats: accumulates per (img, group) sum and sum of squares of (x + addvec[img,c]) in float64 into

@@ -7,20 +7,22 @@
 //
 // Design for gfx950 (wave64, v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains at the fp32 vector rate):
 //   GEMM view   M = output pixels, N = output channels, K = taps x input channels.
-//   block       WAVES_M x WAVES_N waves; wave tile = TM x TN MFMA tiles of 32x32; BM = 32*TM*WAVES_M pixels,
-//               BN = 32*TN*WAVES_N channels.  The BM pixels are NIB images x (TH x TW) spatial tile.
-//   K loop      32 input channels at a time ("chunk").  Per chunk the input halo tile ((TH+2)x(TW+2) pixels x 32
-//               channels) is staged in LDS ONCE and reused by all 9 taps (the A operand of tap (dy,dx) is the same
-//               LDS image read at a shifted pixel), so activations cross L2->LDS ~1.3x instead of 9x.  Weights
-//               stream through a double-buffered [BN][32] LDS tile per (chunk, tap).
-//   operands    lane (i = lane&31, h = lane>>5) holds A[i][k] / B[k][i]; one ds_read_b128 fetches the 4 floats
-//               k = 8*kc + 4*h + {0..3} of row i, which feed 4 consecutive MFMAs (the k order inside a chunk is a
-//               fixed permutation shared by A and B).  16-byte slots are XOR-swizzled by (row>>1)&7 so that a
-//               16-lane ds_read_b128 group touches 16 distinct slots of the 256-byte bank row.
-//   pipeline    global -> registers for the next weight tile (and 1/9 of the next halo) is issued before the
-//               MFMAs of the current tap and written to the other LDS buffer after them; one barrier per tap.
+//   block       WM x WN waves; wave tile = TM x TN MFMA tiles of 32x32; BM = 32*TM*WM pixels, BN = 32*TN*WN channels.
+//               The BM pixels are NIB images x (TH x TW) spatial tile.
+//   A operand   activations.  K is walked in chunks of 32*NSUB input channels.  Per chunk the input halo tile
+//               ((TH+2)x(TW+2) pixels x chunk channels) is staged in LDS ONCE and reused by all 9 taps: the A operand
+//               of tap (dy,dx) is the same LDS image read at a shifted pixel, so activations cross L2->LDS ~1.3x
+//               instead of 9x.  Lane (i = lane&31, h = lane>>5) reads 16 bytes = k in {8kc+4h..+3} of pixel row i with
+//               one ds_read_b128 and feeds them to 4 consecutive MFMAs.  16-byte slots are XOR-swizzled so a 16-lane
+//               read group covers 16 distinct slots of the 256-byte bank row.
+//   B operand   weights, pre-packed ONCE into MFMA-fragment order [c32][n tile][tap][kc][lane][4]: every B fragment is
+//               one fully coalesced 1 KiB global_load_dwordx4 straight into VGPRs (served by L1/L2: co-resident
+//               waves stream the same tiles), prefetched one k-step ahead.  Weights never touch LDS, so the only
+//               workgroup barrier is the halo hand-over once per chunk (= every 9 taps x 4 k-steps), not per tap.
+//   pipeline    next chunk's halo is loaded global->registers one item per tap and parked in the other LDS buffer
+//               behind the MFMAs of that tap.
 //   grid        one block per (m tile, n tile), remapped so that each XCD gets a contiguous, n-major range of
-//               tiles (blocks resident on one XCD stream the same weight tiles through that XCD's L2).
+//               tiles (blocks resident on one XCD stream the same weight fragments through that XCD's L2).
 #include "nd_common.h"
 
 namespace nd {
@@ -28,52 +30,51 @@ namespace nd {
 struct ConvArgs {
     const float* x0;
     const float* x1;
-    const float* w;
+    const float* w;      // packed fragments
     const float* bias;
     const float* rowbias;
     const float* res;
     float* out;
-    int C0, C1, ldx0, ldx1, ldw;
+    int C0, C1, ldx0, ldx1;
     int NI, H, W;      // output (= virtual input) size
     int Hs, Ws;        // stored input size (H >> up)
     int up;            // input read through nearest-2x upsampling
     int res_up;        // residual read through nearest-2x upsampling
     int N, ldo, ldr, ld_rowbias;
+    int NT32;          // ceil(N / 32)
+    int NC32;          // ceil(Cin / 32)
     int thl, twl, nibl;   // log2 of tile height / width / images per block
     int tiles_x, tiles_y, mt, nt;
     int silu_out;
 };
 
-template <int TAPS>
-struct Halo {
-    static constexpr int PAD = (TAPS == 9) ? 1 : 0;
-};
+__host__ __device__ inline int nc32_padded(int C) {
+    const int c = (C + 31) / 32;
+    return (c + 1) & ~1;      // even number of 32-channel chunks (the 1x1 kernel walks two per barrier)
+}
 
-// number of float4 halo items a thread may own (item k of a thread = halo pixel (tid>>3) + k*(NT>>3), slot tid&7)
-template <int BM, int NT, int TAPS>
-struct HaloItems {
-    static constexpr int value = (TAPS == 9) ? 9 : (BM * 8 / NT);
-};
-
-template <int WAVES_M, int WAVES_N, int TM, int TN, int TAPS>
-__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
+template <int WM, int WN, int TM, int TN, int TAPS, int OCC>
+__global__ void __launch_bounds__(WM* WN * 64, OCC)
     conv_mfma_kernel(const ConvArgs p) {
-    constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int BM = WAVES_M * TM * 32;
-    constexpr int BN = WAVES_N * TN * 32;
-    constexpr int PAD = Halo<TAPS>::PAD;
-    constexpr int MAXHI = HaloItems<BM, NT, TAPS>::value;
-    constexpr int HPF = (TAPS == 9) ? 1 : MAXHI;       // halo float4 prefetched per iteration
-    constexpr int WI = BN * 8 / NT;                    // weight float4 per thread per tile
-    static_assert(BN * 8 % NT == 0, "weight tile must divide over the block");
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int NSUB = (TAPS == 9) ? 1 : 2;          // 32-channel sub-chunks per LDS chunk
+    constexpr int SPR = 8 * NSUB;                      // 16-byte slots per halo pixel row
+    constexpr int ROWF = 32 * NSUB;                    // floats per halo pixel row
+    constexpr int STEPS = TAPS * 4;                    // k-steps (8 channels each) per 32-channel chunk
+    constexpr int MAXHI = (TAPS == 9) ? 9 : (BM * SPR / NT);   // halo float4 items per thread per chunk
+    static_assert(TAPS == 9 || MAXHI <= NSUB * 4, "one halo item per k-step");
+    static_assert(NT % SPR == 0, "");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][ROWF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave - wm * WAVES_N;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
@@ -95,15 +96,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
     const int n0 = nblk * BN;
 
-    float* const halo_base = smem;                     // 2 x [HP][32]
-    float* const w_base = smem + 2 * HP * 32;          // 2 x [BN][32]
-
     // ---- halo descriptors: source pixel index of each halo item (or -1 = zero fill)
-    const int hslot = tid & 7;
+    const int hslot = tid % SPR;          // logical 16-byte slot inside the chunk row
+    const int hrow0 = tid / SPR;
     int gpix[MAXHI];
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) {
-        const int hp = (tid >> 3) + k * (NT >> 3);
+        const int hp = hrow0 + k * (NT / SPR);
         int g = -1;
         if (hp < HP) {
             const int li = hp / HPI;
@@ -119,12 +118,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     }
 
     const int Ctot = p.C0 + p.C1;
-    const int nchunks = (Ctot + 31) >> 5;
-    const int nit = nchunks * TAPS;
+    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
 
+    auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
     auto load_halo_item = [&](int k, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = (ch << 5) + (hslot << 2);
+        const int c = ch * ROWF + (hslot << 2);
         const int g = gpix[k];
         if (g >= 0 && c < Ctot) {
             const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
@@ -133,23 +132,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
         return v;
     };
     auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        const int hp = (tid >> 3) + k * (NT >> 3);
+        const int hp = hrow0 + k * (NT / SPR);
         if (hp < HP) {
-            float* dst = halo_base + buf * (HP * 32) + hp * 32 + ((hslot ^ ((hp >> 1) & 7)) << 2);
+            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
             *reinterpret_cast<f32x4*>(dst) = v;
         }
-    };
-    auto load_w_item = [&](int k, int ch, int tap) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int n = n0 + (tid >> 3) + k * (NT >> 3);
-        const int c = (ch << 5) + (hslot << 2);
-        if (n < p.N && c < Ctot) v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tap * p.N + n) * p.ldw + c);
-        return v;
-    };
-    auto store_w_item = [&](int k, int buf, f32x4 v) {
-        const int n = (tid >> 3) + k * (NT >> 3);
-        float* dst = w_base + buf * (BN * 32) + n * 32 + ((hslot ^ ((n >> 1) & 7)) << 2);
-        *reinterpret_cast<f32x4*>(dst) = v;
     };
 
     // ---- per-lane operand rows
@@ -162,10 +149,16 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
         const int px = m & (TW - 1);
         a_hp[mi] = li * HPI + py * HW + px;
     }
-    int b_row[TN];
+    // B fragment stream of n tile ni: [c32][n tile][step][lane][4]; one fragment = 256 floats
+    const float* bp[TN];
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) b_row[ni] = ((wn * TN + ni) * 32 + l31) * 32;
-    const int b_swz = (l31 >> 1) & 7;
+    for (int ni = 0; ni < TN; ++ni) {
+        int ntile = nblk * (BN / 32) + wn * TN + ni;
+        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;      // N tail: results are discarded in the epilogue
+        bp[ni] = p.w + (size_t)ntile * (STEPS * 256) + lane * 4;
+    }
+    const size_t c32_jump = (size_t)(p.NT32 - 1) * (STEPS * 256);   // from the end of one c32 stream to the next
+    int ld_in_c32 = 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -175,91 +168,101 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    // ---- prologue: chunk 0 halo + first weight tile
+    f32x4 b_cur[TN], b_nxt[TN];
+    // the packed buffer carries one zero c32 block of padding at the end, so the stream may always run one ahead
+    auto advance_b = [&]() {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            b_nxt[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+            bp[ni] += 256;
+        }
+        if (++ld_in_c32 == STEPS) {
+            ld_in_c32 = 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bp[ni] += c32_jump;
+        }
+    };
+
+    // ---- prologue: chunk 0 halo, first B fragments
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_item(k, 0));
+    advance_b();
 #pragma unroll
-    for (int k = 0; k < WI; ++k) store_w_item(k, 0, load_w_item(k, 0, 0));
+    for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
     __syncthreads();
 
-    int it = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = halo_base + (ch & 1) * (HP * 32);
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+        if constexpr (TAPS == 9) {
 #pragma unroll 1
-        for (int tap = 0; tap < TAPS; ++tap, ++it) {
-            // -- issue global loads for the next iteration
-            const bool has_next = (it + 1) < nit;
-            const int ntap = (tap + 1 == TAPS) ? 0 : tap + 1;
-            const int nch = (tap + 1 == TAPS) ? ch + 1 : ch;
-            f32x4 pw[WI];
-#pragma unroll
-            for (int k = 0; k < WI; ++k) {
-                pw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (has_next) pw[k] = load_w_item(k, nch, ntap);
-            }
-            const bool halo_next = (ch + 1) < nchunks;
-            f32x4 ph[HPF];
-            if constexpr (TAPS == 9) {
-                ph[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tap = 0; tap < 9; ++tap) {
+                f32x4 ph = {0.f, 0.f, 0.f, 0.f};
                 if (halo_next) {
-                    // item `tap` of the next chunk's halo (MAXHI == 9: one item per tap)
 #pragma unroll
                     for (int k = 0; k < MAXHI; ++k)
-                        if (k == tap) ph[0] = load_halo_item(k, ch + 1);
+                        if (k == tap) ph = load_halo_item(k, ch + 1);
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < HPF; ++k) {
-                    ph[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (halo_next) ph[k] = load_halo_item(k, ch + 1);
-                }
-            }
-
-            // -- MFMAs of this (chunk, tap)
-            const float* wbuf = w_base + (it & 1) * (BN * 32);
-            int tapoff = 0;
-            if constexpr (TAPS == 9) {
                 const int dy = tap / 3;
-                tapoff = dy * HW + (tap - dy * 3);
-            }
+                const int tapoff = dy * HW + (tap - dy * 3);
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int slot = (kc << 1) | lh;
-                f32x4 a[TM], b[TN];
+                for (int kc = 0; kc < 4; ++kc) {
+                    advance_b();
+                    const int slot = (kc << 1) | lh;
+                    f32x4 a[TM];
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int hp = a_hp[mi] + tapoff;
-                    a[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * 32 + ((slot ^ ((hp >> 1) & 7)) << 2));
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int hp = a_hp[mi] + tapoff;
+                        a[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < TN; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
                 }
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    b[ni] = *reinterpret_cast<const f32x4*>(wbuf + b_row[ni] + ((slot ^ b_swz) << 2));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-            }
-
-            // -- park the prefetched tiles in the other LDS buffers
-            if (has_next) {
-#pragma unroll
-                for (int k = 0; k < WI; ++k) store_w_item(k, (it + 1) & 1, pw[k]);
-            }
-            if (halo_next) {
-                if constexpr (TAPS == 9) {
+                if (halo_next) {
 #pragma unroll
                     for (int k = 0; k < MAXHI; ++k)
-                        if (k == tap) store_halo_item(k, (ch + 1) & 1, ph[0]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < HPF; ++k) store_halo_item(k, (ch + 1) & 1, ph[k]);
+                        if (k == tap) store_halo_item(k, (ch + 1) & 1, ph);
                 }
             }
-            __syncthreads();
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                if (ch * NSUB + sub < p.NC32) {
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const int item = sub * 4 + kc;
+                        f32x4 ph = {0.f, 0.f, 0.f, 0.f};
+                        if (item < MAXHI && halo_next) ph = load_halo_item(item < MAXHI ? item : 0, ch + 1);
+                        advance_b();
+                        const int slot = (sub << 3) | (kc << 1) | lh;
+                        f32x4 a[TM];
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) {
+                            const int hp = a_hp[mi];
+                            a[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < TN; ++ni)
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
+                        if (item < MAXHI && halo_next) store_halo_item(item < MAXHI ? item : 0, (ch + 1) & 1, ph);
+                    }
+                }
+            }
         }
+        __syncthreads();
     }
 
     // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -293,30 +296,56 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     }
 }
 
+// Weights [N][C][k][k] (OIHW; also Conv1d [N][C][1] and Linear [N][C]) -> fragment order
+//   out[((((c32*NT32 + ntile)*taps + tap)*4 + kc)*64 + lane)*4 + j] = w[n = ntile*32 + (lane&31)][c = c32*32 + kc*8 + (lane>>5)*4 + j][tap]
+// zero for n >= N, c >= C, and for the padding chunks (c32 in [ceil(C/32), nc32_padded(C)]).
+__global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C, int taps, int NT32, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(it & 3);
+        const int lane = (int)((it >> 2) & 63);
+        long r = it >> 8;
+        const int kc = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % taps);
+        r /= taps;
+        const int ntile = (int)(r % NT32);
+        const int c32 = (int)(r / NT32);
+        const int n = ntile * 32 + (lane & 31);
+        const int c = c32 * 32 + kc * 8 + (lane >> 5) * 4 + j;
+        out[it] = (n < N && c < C) ? w[((size_t)n * C + c) * taps + tap] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side: tile-shape variants and launch
 // ------------------------------------------------------------------------------------------------------------
 struct Variant {
-    int wm, wn, tm, tn;
+    int wm, wn, tm, tn, occ;     // occ = blocks per CU the kernel is compiled for (waves/SIMD = occ * waves / 4)
     int bm() const { return wm * tm * 32; }
     int bn() const { return wn * tn * 32; }
     int nt() const { return wm * wn * 64; }
 };
 
 static const Variant kVariants[] = {
-    {4, 2, 2, 3},   // 0: 256 x 192, 8 waves
-    {4, 2, 2, 2},   // 1: 256 x 128, 8 waves
-    {2, 2, 2, 3},   // 2: 128 x 192, 4 waves
-    {4, 1, 1, 3},   // 3: 128 x  96, 4 waves
-    {2, 2, 2, 1},   // 4: 128 x  64, 4 waves
-    {2, 2, 1, 1},   // 5:  64 x  64, 4 waves
-    {2, 1, 1, 1},   // 6:  64 x  32, 2 waves
+    {4, 2, 2, 3, 1},   // 0: 256 x 192, 8 waves, 1 block / CU
+    {2, 2, 2, 3, 2},   // 1: 128 x 192, 4 waves, 2 blocks / CU
+    {4, 2, 2, 2, 1},   // 2: 256 x 128, 8 waves
+    {2, 2, 2, 2, 2},   // 3: 128 x 128, 4 waves, 2 blocks / CU
+    {4, 1, 1, 3, 3},   // 4: 128 x  96, 4 waves, 3 blocks / CU
+    {2, 2, 1, 3, 3},   // 5:  64 x 192, 4 waves, 3 blocks / CU
+    {2, 2, 2, 1, 2},   // 6: 128 x  64, 4 waves
+    {2, 2, 1, 1, 4},   // 7:  64 x  64, 4 waves
+    {2, 1, 1, 1, 4},   // 8:  64 x  32, 2 waves
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-template <int WM, int WN, int TM, int TN, int TAPS>
+template <int WM, int WN, int TM, int TN, int TAPS, int OCC>
 static int launch_variant(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_mfma_kernel<WM, WN, TM, TN, TAPS>;
+    if constexpr (TAPS == 1 && (WM * TM * 32 * 16) / (WM * WN * 64) > 8) {
+        set_error("nd_conv_nhwc: this variant has no 1x1 form");
+        return ND_E_ARG;
+    } else {
+    auto kern = conv_mfma_kernel<WM, WN, TM, TN, TAPS, (OCC * WM * WN + 3) / 4>;
     static bool attr_set = false;   // one flag per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -329,18 +358,21 @@ static int launch_variant(const ConvArgs& a, int grid, size_t lds, hipStream_t s
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
     return check_launch("nd_conv_nhwc");
+    }
 }
 
 template <int TAPS>
 static int dispatch(int v, const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (v) {
-        case 0: return launch_variant<4, 2, 2, 3, TAPS>(a, grid, lds, s);
-        case 1: return launch_variant<4, 2, 2, 2, TAPS>(a, grid, lds, s);
-        case 2: return launch_variant<2, 2, 2, 3, TAPS>(a, grid, lds, s);
-        case 3: return launch_variant<4, 1, 1, 3, TAPS>(a, grid, lds, s);
-        case 4: return launch_variant<2, 2, 2, 1, TAPS>(a, grid, lds, s);
-        case 5: return launch_variant<2, 2, 1, 1, TAPS>(a, grid, lds, s);
-        case 6: return launch_variant<2, 1, 1, 1, TAPS>(a, grid, lds, s);
+        case 0: return launch_variant<4, 2, 2, 3, TAPS, 1>(a, grid, lds, s);
+        case 1: return launch_variant<2, 2, 2, 3, TAPS, 2>(a, grid, lds, s);
+        case 2: return launch_variant<4, 2, 2, 2, TAPS, 1>(a, grid, lds, s);
+        case 3: return launch_variant<2, 2, 2, 2, TAPS, 2>(a, grid, lds, s);
+        case 4: return launch_variant<4, 1, 1, 3, TAPS, 3>(a, grid, lds, s);
+        case 5: return launch_variant<2, 2, 1, 3, TAPS, 3>(a, grid, lds, s);
+        case 6: return launch_variant<2, 2, 2, 1, TAPS, 2>(a, grid, lds, s);
+        case 7: return launch_variant<2, 2, 1, 1, TAPS, 4>(a, grid, lds, s);
+        case 8: return launch_variant<2, 1, 1, 1, TAPS, 4>(a, grid, lds, s);
     }
     set_error("nd_conv_nhwc: bad variant %d", v);
     return ND_E_ARG;
@@ -357,6 +389,8 @@ static int ilog2(int v) {
     return l;
 }
 
+static size_t lds_bytes(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 32 : 64) * sizeof(float); }
+
 // Choose TH x TW x NIB = BM minimising padded pixels, then halo size.
 static bool plan_tiles(int bm, int nt, int taps, int NI, int H, int W, TilePlan* best) {
     const int lbm = ilog2(bm);
@@ -367,8 +401,10 @@ static bool plan_tiles(int bm, int nt, int taps, int NI, int H, int W, TilePlan*
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2 * pad) * (TW + 2 * pad);
-            const int maxhi = taps == 9 ? 9 : bm * 8 / nt;
-            if (hp * 8 > maxhi * nt) continue;
+            const int spr = taps == 9 ? 8 : 16;
+            const int maxhi = taps == 9 ? 9 : bm * spr / nt;
+            if ((long)hp * spr > (long)maxhi * nt) continue;
+            if (lds_bytes(taps, hp) > 160 * 1024) continue;
             TilePlan t;
             t.thl = thl; t.twl = twl; t.nibl = nibl;
             t.tiles_x = (W + TW - 1) / TW;
@@ -385,34 +421,27 @@ static bool plan_tiles(int bm, int nt, int taps, int NI, int H, int W, TilePlan*
     return found;
 }
 
-}  // namespace nd
-
-
-// Choose the tile-shape variant (and its spatial tiling) for a problem: minimise
-//   ceil(blocks / slots) * tile cost,   slots = CUs x blocks/CU that fit LDS and the wave budget.
-static int select_variant(int variant, int taps, int pNI, int pH, int pW, int N, nd::TilePlan* out_tp) {
-    using namespace nd;
+// Choose the tile-shape variant (and its spatial tiling) for a problem from a cost model:
+//   rounds of blocks over the CU slots x tile cost.  (The Python plan builder overrides this by measuring.)
+static int select_variant(int variant, int taps, int pNI, int pH, int pW, int N, TilePlan* out_tp) {
     int best_v = -1;
     TilePlan best_tp{};
     double best_cost = 0;
     for (int v = 0; v < kNumVariants; ++v) {
         if (variant >= 0 && v != variant) continue;
         const Variant& V = kVariants[v];
+        if (taps != 9 && V.bm() * 16 / V.nt() > 8) continue;      // 1x1: one halo item per k-step
         TilePlan tp;
         if (!plan_tiles(V.bm(), V.nt(), taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
         const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = (size_t)(2 * tp.hp + 2 * V.bn()) * 128;
-        if (lds > 160 * 1024) continue;
+        const size_t lds = lds_bytes(taps, tp.hp);
         int per_cu = (int)(160 * 1024 / lds);
-        const int wave_cap = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;   // keep <= 2 waves / SIMD
-        if (per_cu > wave_cap) per_cu = wave_cap;
+        if (per_cu > V.occ) per_cu = V.occ;
         if (per_cu < 1) per_cu = 1;
         const long slots = 256L * per_cu;
         const long rounds = (nblocks + slots - 1) / slots;
-        // cost of one round: a CU runs per_cu blocks concurrently sharing its 4 matrix pipes
         double cost = (double)rounds * per_cu * V.bm() * V.bn();
-        // small wave tiles re-read operands from LDS more often and have less MFMA back-to-back: mild penalty
         const double eff = (V.tm * V.tn >= 4) ? 1.0 : (V.tm * V.tn >= 2 ? 0.93 : 0.85);
         cost /= eff;
         if (best_v < 0 || cost < best_cost * 0.999) {
@@ -428,25 +457,44 @@ static bool use_flat(int taps, int flags, const float* rowbias) {
     return taps == 1 && !(flags & (ND_CONV_IN_UP2X | ND_CONV_RES_UP2X)) && rowbias == nullptr;
 }
 
+}  // namespace nd
+
 using namespace nd;
 
 extern "C" int nd_conv_num_variants(void) { return kNumVariants; }
 
+extern "C" int64_t nd_conv_weight_floats(int N, int C, int ksize) {
+    if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3)) return ND_E_ARG;
+    const int64_t nt32 = (N + 31) / 32;
+    return (int64_t)(nc32_padded(C) + 1) * nt32 * ksize * ksize * 4 * 256;
+}
+
+extern "C" int nd_repack_conv_weight(const float* w, float* w_out, int N, int C, int ksize, nd_stream_t stream) {
+    const char* fn = "nd_repack_conv_weight";
+    ND_REQUIRE(w && w_out && N > 0 && C > 0 && (ksize == 1 || ksize == 3), fn, "bad arguments");
+    const long total = (long)nd_conv_weight_floats(N, C, ksize);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                       w_out, N, C, ksize * ksize, (N + 31) / 32, total);
+    return check_launch(fn);
+}
+
 extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                            const float* w, int ldw, const float* bias, const float* rowbias, int ld_rowbias,
+                            const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                             const float* residual, int ldr, float* out, int ldo,
                             int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream) {
     const char* fn = "nd_conv_nhwc";
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
-    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0 && (ldw & 3) == 0, fn,
+    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0, fn,
                "channel counts and strides must be multiples of 4");
-    ND_REQUIRE(ldx0 >= C0 && ldw >= C0 + C1 && ldo >= N, fn, "stride smaller than channel count");
+    ND_REQUIRE(ldx0 >= C0 && ldo >= N, fn, "stride smaller than channel count");
     ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
     if (C1 > 0) {
-        ND_REQUIRE(x1 != nullptr && (C0 & 31) == 0 && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn,
-                   "two-source input needs C0 % 32 == 0 and an aligned x1");
+        ND_REQUIRE(x1 != nullptr && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn,
+                   "two-source input needs an aligned x1 with ldx1 >= C1");
     }
     const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
     const int res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;
@@ -458,7 +506,6 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
 
     const int taps = ksize * ksize;
     const long M = (long)NI * H * W;
-    // 1x1: the spatial structure is irrelevant -> flat pixel list (keeps tiles dense for odd image sizes)
     int pNI = NI, pH = H, pW = W;
     const bool flat = use_flat(taps, flags, rowbias);
     if (flat) { pNI = 1; pH = 1; pW = (int)M; }
@@ -470,18 +517,20 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const Variant& V = kVariants[best_v];
     ConvArgs a;
     a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
-    a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0; a.ldw = ldw;
+    a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
     a.NI = pNI; a.H = pH; a.W = pW;
     a.up = up; a.res_up = res_up;
     a.Hs = pH >> up; a.Ws = pW >> up;
     a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
+    a.NT32 = (N + 31) / 32;
+    a.NC32 = (C0 + C1 + 31) / 32;
     a.thl = best_tp.thl; a.twl = best_tp.twl; a.nibl = best_tp.nibl;
     a.tiles_x = best_tp.tiles_x; a.tiles_y = best_tp.tiles_y;
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     const int grid = a.mt * a.nt;
-    const size_t lds = (size_t)(2 * best_tp.hp + 2 * V.bn()) * 128;
+    const size_t lds = lds_bytes(taps, best_tp.hp);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
 }

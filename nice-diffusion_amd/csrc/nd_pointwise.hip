@@ -94,19 +94,8 @@ __global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int C, int HW,
     }
 }
 
-// ---- weights -------------------------------------------------------------------------------------------------
-__global__ void repack_conv_weight_kernel(const float* w, float* out, int N, int C, int taps, int ldw, long total) {
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(it % ldw);
-        long r = it / ldw;
-        const int n = (int)(r % N);
-        const int tap = (int)(r / N);
-        out[it] = (c < C) ? w[((size_t)n * C + c) * taps + tap] : 0.f;
-    }
-}
-
 // ---- direct convolution (one thread per output element; only for the non-preset stride-2 Downsample conv) -----
-__global__ void conv_direct_kernel(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+__global__ void conv_direct_kernel(const float* x, int C, int ldx, const float* w, const float* bias,
                                    float* out, int ldo, int H, int W, int Ho, int Wo, int N, int ks, int stride,
                                    int pad, long total) {
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -124,15 +113,8 @@ __global__ void conv_direct_kernel(const float* x, int C, int ldx, const float* 
                 const int ix = ox * stride - pad + kx;
                 if (ix < 0 || ix >= W) continue;
                 const float* xp = x + ((size_t)(img * H + iy) * W + ix) * ldx;
-                const float* wp = w + ((size_t)(ky * ks + kx) * N + n) * ldw;
-                for (int c = 0; c < C; c += 4) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + c);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(wp + c);
-                    acc = fmaf(a[0], b[0], acc);
-                    acc = fmaf(a[1], b[1], acc);
-                    acc = fmaf(a[2], b[2], acc);
-                    acc = fmaf(a[3], b[3], acc);
-                }
+                const float* wp = w + (size_t)n * C * ks * ks + ky * ks + kx;      // OIHW
+                for (int c = 0; c < C; ++c) acc = fmaf(xp[c], wp[(size_t)c * ks * ks], acc);
             }
         }
         out[((size_t)(img * Ho + oy) * Wo + ox) * ldo + n] = acc;
@@ -224,29 +206,17 @@ extern "C" int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int 
     return check_launch(fn);
 }
 
-extern "C" int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, int ldw,
-                                     nd_stream_t stream) {
-    const char* fn = "nd_repack_conv_weight";
-    ND_REQUIRE(w_oihw && w_out && N > 0 && C > 0 && ksize > 0 && ldw >= C, fn, "bad arguments");
-    const int taps = ksize * ksize;
-    const long total = (long)taps * N * ldw;
-    hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), w_oihw,
-                       w_out, N, C, taps, ldw, total);
-    return check_launch(fn);
-}
-
-extern "C" int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w, int ldw, const float* bias,
+extern "C" int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, const float* bias,
                                    float* out, int ldo, int NI, int H, int W, int N, int ksize, int stride, int pad,
                                    nd_stream_t stream) {
     const char* fn = "nd_conv_direct_nhwc";
-    ND_REQUIRE(x && w && out && NI > 0 && H > 0 && W > 0 && N > 0 && C > 0, fn, "bad arguments");
+    ND_REQUIRE(x && w_oihw && out && NI > 0 && H > 0 && W > 0 && N > 0 && C > 0 && ldx >= C, fn, "bad arguments");
     ND_REQUIRE(ksize >= 1 && stride >= 1 && pad >= 0, fn, "bad conv geometry");
-    ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && aligned16(x) && aligned16(w), fn, "alignment");
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     ND_REQUIRE(Ho > 0 && Wo > 0 && ldo >= N, fn, "bad output shape");
     const long total = (long)NI * Ho * Wo * N;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, C, ldx, w,
-                       ldw, bias, out, ldo, H, W, Ho, Wo, N, ksize, stride, pad, total);
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, C, ldx,
+                       w_oihw, bias, out, ldo, H, W, Ho, Wo, N, ksize, stride, pad, total);
     return check_launch(fn);
 }
 

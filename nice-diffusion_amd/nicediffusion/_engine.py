@@ -80,6 +80,7 @@ class UNetPlan:
         self.meta = []          # per launch: label, entry point, algorithmic flops, conv tile variant
         self.keep = []          # tensors that must outlive the plan (packed weights, etc.)
         self.pool = _Pool(dev)
+        self.packed_floats = 0
         self.flops = 0          # algorithmic flops of the MFMA launches (2 per MAC)
         self.conv_flops = {}    # label -> flops
         R = model.resolution
@@ -111,22 +112,31 @@ class UNetPlan:
         if act is not None and act.t is not None:
             self.pool.give(act.t)
 
-    def _packed_conv3(self, weight):
-        """OIHW -> [9][N][Cin_pad4] once, on the device."""
-        N, C, k, _ = weight.shape
-        ldw = _pad4(C)
-        out = torch.empty(k * k * N * ldw, dtype=torch.float32, device=self.device)
-        w = weight.detach().contiguous()
-        _hip.check(self.lib.nd_repack_conv_weight(w.data_ptr(), out.data_ptr(), N, C, k, ldw, self._stream()),
+    def _packed(self, weight, pad_c_to=None):
+        """Conv2d [N,C,k,k] / Conv1d [N,C,1] / Linear [N,C] weight -> MFMA-fragment order, once, on the device.
+        ``pad_c_to``: treat the weight as having that many input channels (zero columns appended)."""
+        w = weight.detach()
+        N, C = w.shape[0], w.shape[1]
+        k = w.shape[2] if w.dim() == 4 else 1
+        w = w.contiguous()
+        if pad_c_to is not None and pad_c_to != C:
+            wp = torch.zeros((N, pad_c_to) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            wp[:, :C] = w
+            w, C = wp, pad_c_to
+        n = self.lib.nd_conv_weight_floats(N, C, k)
+        assert n > 0
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.nd_repack_conv_weight(w.data_ptr(), out.data_ptr(), N, C, k, self._stream()),
                    'nd_repack_conv_weight')
         self.keep.append(out)
-        return out, ldw
+        self.packed_floats += n
+        return out
 
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
-    def conv(self, src, w_ptr, ldw, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
+    def conv(self, src, w_ptr, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
              residual=None, flags=0, label='conv'):
         """Emit nd_conv_nhwc.  ``src`` (and optional ``src2``) are Acts; output spatial size is src's, doubled when
         CONV_IN_UP2X is set."""
@@ -136,7 +146,7 @@ class UNetPlan:
             out = self._new(NI, H, W, N)
         C1 = 0 if src2 is None else src2.C
         args = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld,
-                w_ptr, ldw, bias, rowbias, ld_rowbias,
+                w_ptr, bias, rowbias, ld_rowbias,
                 None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                 out.ptr, out.ld, NI, H, W, N, ksize, flags, -1]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
@@ -179,9 +189,9 @@ class UNetPlan:
         return best
 
     def linear(self, src_ptr, M, K, weight, bias, out_ptr, N, flags=0, label='linear'):
-        w = weight.detach()
-        assert w.is_contiguous() and K % 4 == 0
-        args = [src_ptr, K, K, None, 0, 0, w.data_ptr(), K, None if bias is None else bias.detach().data_ptr(),
+        assert K % 4 == 0
+        args = [src_ptr, K, K, None, 0, 0, self._packed(weight).data_ptr(),
+                None if bias is None else bias.detach().data_ptr(),
                 None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1]
         var = self.lib.nd_conv_select_variant(1, 1, M, N, 1, flags, 0)
         self._emit(self.lib.nd_conv_nhwc, args, label, flops=2 * M * N * K, variant=var, ksize=1)
@@ -249,7 +259,7 @@ class UNetPlan:
             self.e_w = torch.cat([rb.step_embedding.weight.detach() for rb in res_blocks], 0).contiguous()
             self.e_b = torch.cat([rb.step_embedding.bias.detach() for rb in res_blocks], 0).contiguous()
             self.e_all = torch.empty(NI * self.e_ld, **f32)
-            args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self.e_w.data_ptr(), ed, self.e_b.data_ptr(),
+            args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self._packed(self.e_w).data_ptr(), self.e_b.data_ptr(),
                     None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1]
             var = lib.nd_conv_select_variant(1, 1, NI, self.e_ld, 1, 0, 0)
             self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=var, ksize=1)
@@ -269,9 +279,9 @@ class UNetPlan:
         # output head: GN -> SiLU -> conv3x3 (model.py:446-449)
         h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
         self._release(x_cur)
-        wp, ldw = self._packed_conv3(m.out[2].weight)
         out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
-        self.conv(h, wp.data_ptr(), ldw, m.out[2].bias.detach().data_ptr(), self.Cout, 3, out=out_act, label='conv3x3')
+        self.conv(h, self._packed(m.out[2].weight).data_ptr(), m.out[2].bias.detach().data_ptr(), self.Cout, 3,
+                  out=out_act, label='conv3x3')
         self._release(h)
 
         # ---- GroupNorm statistics arena (float64 [slots][NI][32][2]); zeroed at the start of every run
@@ -301,8 +311,8 @@ class UNetPlan:
                 nxt = self._attn_block(layer, cur)
             elif isinstance(layer, torch.nn.Conv2d):
                 assert cur2 is None
-                wp, ldw = self._packed_conv3(layer.weight)
-                nxt = self.conv(cur, wp.data_ptr(), ldw, layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
+                wp = self._packed(layer.weight, pad_c_to=cur.C)
+                nxt = self.conv(cur, wp.data_ptr(), layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
                                 label='conv3x3')
             elif isinstance(layer, M.Downsample):
                 assert cur2 is None
@@ -330,9 +340,9 @@ class UNetPlan:
         # h = silu(in_norm(x)); 'down' pools here, 'up' is folded into the conv's input addressing
         h0 = self.groupnorm(x, rb.in_norm, src2=x2, silu=True, pool=(mode == 'down'), label='res.in_norm')
         e_ptr = self.e_all.data_ptr() + 4 * self.e_off[id(rb)]
-        wp, ldw = self._packed_conv3(rb.in_conv.weight)
+        wp = self._packed(rb.in_conv.weight)
         adaptive = rb.use_adaptive_gn
-        h1 = self.conv(h0, wp.data_ptr(), ldw, rb.in_conv.bias.detach().data_ptr(), Cout, 3,
+        h1 = self.conv(h0, wp.data_ptr(), rb.in_conv.bias.detach().data_ptr(), Cout, 3,
                        rowbias=None if adaptive else e_ptr, ld_rowbias=0 if adaptive else self.e_ld,
                        flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
         self._release(h0)
@@ -354,14 +364,9 @@ class UNetPlan:
             xs, xs2 = x, x2
         if isinstance(rb.skip, torch.nn.Conv2d):
             k = rb.skip.weight.shape[-1]
-            if k == 1:
-                w = rb.skip.weight.detach()
-                s = self.conv(xs, w.data_ptr(), Cin, rb.skip.bias.detach().data_ptr(), Cout, 1, src2=xs2,
-                              flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv1x1')
-            else:
-                wps, ldws = self._packed_conv3(rb.skip.weight)
-                s = self.conv(xs, wps.data_ptr(), ldws, rb.skip.bias.detach().data_ptr(), Cout, 3, src2=xs2,
-                              flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
+            s = self.conv(xs, self._packed(rb.skip.weight).data_ptr(), rb.skip.bias.detach().data_ptr(), Cout, k,
+                          src2=xs2, flags=_hip.CONV_IN_UP2X if mode == 'up' else 0,
+                          label='conv1x1' if k == 1 else 'conv3x3')
             if tmp is not None:
                 self._release(tmp)
             tmp = s
@@ -371,8 +376,8 @@ class UNetPlan:
             res = xs
             if mode == 'up':
                 flags |= _hip.CONV_RES_UP2X
-        wp2, ldw2 = self._packed_conv3(rb.out_conv.weight)
-        out = self.conv(h2, wp2.data_ptr(), ldw2, rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
+        wp2 = self._packed(rb.out_conv.weight)
+        out = self.conv(h2, wp2.data_ptr(), rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
                         flags=flags, label='conv3x3')
         self._release(h2)
         if tmp is not None:
@@ -384,8 +389,8 @@ class UNetPlan:
         NI, H, W, C = x.NI, x.H, x.W, x.C
         T = H * W
         n = self.groupnorm(x, ab.norm, silu=False, label='attn.norm')
-        wq = ab.qkv_nin.weight.detach()
-        qkv = self.conv(n, wq.data_ptr(), C, ab.qkv_nin.bias.detach().data_ptr(), 3 * C, 1, label='conv1x1')
+        qkv = self.conv(n, self._packed(ab.qkv_nin.weight).data_ptr(), ab.qkv_nin.bias.detach().data_ptr(), 3 * C, 1,
+                        label='conv1x1')
         self._release(n)
         a = self._new(NI, H, W, C)
         nh = ab.num_heads
@@ -400,8 +405,8 @@ class UNetPlan:
         self.flops += 4 * NI * nh * T * T * hd
         self.conv_flops['attention'] = self.conv_flops.get('attention', 0) + 4 * NI * nh * T * T * hd
         self._release(qkv)
-        wp = ab.proj_out.weight.detach()
-        out = self.conv(a, wp.data_ptr(), C, ab.proj_out.bias.detach().data_ptr(), C, 1, residual=x, label='conv1x1')
+        out = self.conv(a, self._packed(ab.proj_out.weight).data_ptr(), ab.proj_out.bias.detach().data_ptr(), C, 1,
+                        residual=x, label='conv1x1')
         self._release(a)
         return out
 
@@ -410,10 +415,11 @@ class UNetPlan:
         NI = x.NI
         if layer.with_conv:
             N = layer.conv.weight.shape[0]
-            wp, ldw = self._packed_conv3(layer.conv.weight)
+            w = layer.conv.weight.detach()
+            assert w.is_contiguous()
             Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
             out = self._new(NI, Ho, Wo, N)
-            self._emit(self.lib.nd_conv_direct_nhwc, [x.ptr, x.C, x.ld, wp.data_ptr(), ldw,
+            self._emit(self.lib.nd_conv_direct_nhwc, [x.ptr, x.C, x.ld, w.data_ptr(),
                                                       layer.conv.bias.detach().data_ptr(), out.ptr, out.ld, NI, x.H,
                                                       x.W, N, 3, 2, 1], 'conv_s2')
             return out
@@ -426,8 +432,7 @@ class UNetPlan:
         NI = x.NI
         if layer.with_conv:
             N = layer.conv.weight.shape[0]
-            wp, ldw = self._packed_conv3(layer.conv.weight)
-            return self.conv(x, wp.data_ptr(), ldw, layer.conv.bias.detach().data_ptr(), N, 3,
+            return self.conv(x, self._packed(layer.conv.weight).data_ptr(), layer.conv.bias.detach().data_ptr(), N, 3,
                              flags=_hip.CONV_IN_UP2X, label='conv3x3')
         out = self._new(NI, 2 * x.H, 2 * x.W, x.C)
         self._emit(self.lib.nd_upsample2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'upsample')

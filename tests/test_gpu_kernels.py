@@ -34,13 +34,15 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-def pack_w(w):      # OIHW cpu -> [k*k][N][Cpad] device, via the library's own repack kernel
-    N, C, k, _ = w.shape
-    ldw = (C + 3) // 4 * 4
-    out = torch.empty(k * k * N * ldw, device=DEV)
+def pack_w(w):      # [N,C,k,k] or [N,C] cpu -> MFMA-fragment order on the device, via the library's own repack kernel
+    N, C = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    n = lib().nd_conv_weight_floats(N, C, k)
+    assert n > 0
+    out = torch.full((n,), float('nan'), device=DEV)
     wd = w.contiguous().to(DEV)
-    _hip.check(lib().nd_repack_conv_weight(wd.data_ptr(), out.data_ptr(), N, C, k, ldw, st()))
-    return out, ldw
+    _hip.check(lib().nd_repack_conv_weight(wd.data_ptr(), out.data_ptr(), N, C, k, st()))
+    return out
 
 
 def test_arch_and_version():
@@ -48,12 +50,19 @@ def test_arch_and_version():
     _hip.require_gfx950(0)
 
 
-def test_repack_conv_weight():
-    w = rnd(5, 3, 3, 3)
-    out, ldw = pack_w(w)
-    ref = torch.zeros(9, 5, 4)
-    ref[:, :, :3] = w.permute(2, 3, 0, 1).reshape(9, 5, 3)
-    assert torch.equal(out.cpu().view(9, 5, 4), ref)
+@pytest.mark.parametrize('N,C,k', [(5, 3, 3), (40, 70, 3), (33, 64, 1), (6, 192, 3)])
+def test_repack_conv_weight(N, C, k):
+    """[c32][n tile][tap][kc][lane][4] with lane = (n % 32) + 32*h, channel = c32*32 + kc*8 + h*4 + j; zero padded."""
+    w = rnd(N, C, k, k)
+    out = pack_w(w).cpu()
+    nc32 = ((C + 31) // 32 + 1) // 2 * 2 + 1          # even number of chunks + one block of read-ahead padding
+    nt32 = (N + 31) // 32
+    assert out.numel() == nc32 * nt32 * k * k * 4 * 256
+    o = out.view(nc32, nt32, k * k, 4, 2, 32, 4)       # c32, ntile, tap, kc, h, n%32, j
+    wpad = torch.zeros(nt32 * 32, nc32 * 32, k * k)
+    wpad[:N, :C] = w.reshape(N, C, k * k)
+    ref = wpad.view(nt32, 32, nc32, 4, 2, 4, k * k).permute(2, 0, 6, 3, 4, 1, 5)
+    assert torch.equal(o, ref)
 
 
 CONV_CASES = [
@@ -67,11 +76,11 @@ CONV_CASES = [
 def test_conv3x3_all_variants(B, Cin, Cout, H, W):
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
     ref = F.conv2d(x, w, b, padding=1)
-    xd, (wd, ldw), bd = nhwc(x), pack_w(w), b.to(DEV)
+    xd, wd, bd = nhwc(x), pack_w(w), b.to(DEV)
     ran = 0
     for v in [-1] + list(range(lib().nd_conv_num_variants())):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
-        rc = lib().nd_conv_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), ldw, bd.data_ptr(), None, 0, None, 0,
+        rc = lib().nd_conv_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
                                 out.data_ptr(), Cout, B, H, W, Cout, 3, 0, v, st())
         if rc != 0 and v >= 0:
             continue        # this tile shape does not fit this problem
@@ -90,10 +99,10 @@ def test_conv3x3_fused_options():
     w, b = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.05), rnd(Cout, seed=4)
     rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
     ref = F.conv2d(torch.cat([xa, xb], 1), w, b, padding=1) + rb[:, :, None, None] + res
-    (wd, ldw) = pack_w(w)
+    wd = pack_w(w)
     out = torch.empty(B * H * W * Cout, device=DEV)
     xad, xbd, bd, rbd, resd = nhwc(xa), nhwc(xb), b.to(DEV), rb.to(DEV), nhwc(res)
-    _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), ldw, bd.data_ptr(),
+    _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
                                   rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W, Cout, 3, 0,
                                   -1, st()))
     assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
@@ -102,23 +111,24 @@ def test_conv3x3_fused_options():
     w2 = rnd(Cout, C0, 3, 3, seed=9, scale=0.05)
     up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
     ref = F.conv2d(up(x), w2, b, padding=1) + up(r)
-    (wd2, ldw2) = pack_w(w2)
+    wd2 = pack_w(w2)
     out = torch.empty(B * 4 * H * W * Cout, device=DEV)
     xd, rd = nhwc(x), nhwc(r)
-    _hip.check(lib().nd_conv_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), ldw2, bd.data_ptr(), None, 0,
+    _hip.check(lib().nd_conv_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
                                   rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout, 3,
                                   _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, -1, st()))
     assert (from_nhwc(out, B, 2 * H, 2 * W, Cout) - ref).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize('M,K,N', [(2, 32, 128), (64, 768, 1000), (196 * 3, 64, 192), (4096, 384, 1152), (3, 128, 6)])
+@pytest.mark.parametrize('M,K,N', [(2, 32, 128), (64, 768, 1000), (196 * 3, 64, 192), (4096, 384, 1152), (3, 128, 6),
+                                   (70, 100, 40), (300, 96, 96)])
 def test_gemm_1x1_and_silu(M, K, N):
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
     res = rnd(M, N, seed=4)
-    ad, wd, bd, resd = a.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV)
+    ad, wd, bd, resd = a.to(DEV), pack_w(w), b.to(DEV), res.to(DEV)
     for v in [-1] + list(range(lib().nd_conv_num_variants())):
         out = torch.full((M * N,), float('nan'), device=DEV)
-        rc = lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), K, bd.data_ptr(), None, 0,
+        rc = lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                 resd.data_ptr(), N, out.data_ptr(), N, 1, 1, M, N, 1, 0, v, st())
         if rc != 0 and v >= 0:
             continue
@@ -126,7 +136,7 @@ def test_gemm_1x1_and_silu(M, K, N):
         ref = F.linear(a, w, b) + res
         assert (out.cpu().view(M, N) - ref).abs().max().item() < 2e-4, v
     out = torch.empty(M * N, device=DEV)
-    _hip.check(lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), K, bd.data_ptr(), None, 0, None, 0,
+    _hip.check(lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
                                   out.data_ptr(), N, 1, 1, M, N, 1, _hip.CONV_SILU_OUT, -1, st()))
     assert (out.cpu().view(M, N) - F.silu(F.linear(a, w, b))).abs().max().item() < 2e-4
 
@@ -135,9 +145,9 @@ def test_conv_direct_stride2():
     B, C, N, H, W = 2, 32, 48, 16, 16
     x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 3, 3, seed=2, scale=0.05), rnd(N, seed=3)
     ref = F.conv2d(x, w, b, stride=2, padding=1)
-    xd, (wd, ldw), bd = nhwc(x), pack_w(w), b.to(DEV)
+    xd, wd, bd = nhwc(x), w.contiguous().to(DEV), b.to(DEV)
     out = torch.empty(B * 8 * 8 * N, device=DEV)
-    _hip.check(lib().nd_conv_direct_nhwc(xd.data_ptr(), C, C, wd.data_ptr(), ldw, bd.data_ptr(), out.data_ptr(), N, B, H,
+    _hip.check(lib().nd_conv_direct_nhwc(xd.data_ptr(), C, C, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, B, H,
                                          W, N, 3, 2, 1, st()))
     assert (from_nhwc(out, B, 8, 8, N) - ref).abs().max().item() < 1e-4
 
