@@ -121,16 +121,18 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
 
     auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
-    auto load_halo_item = [&](int k, int ch) -> f32x4 {
+    // g = source pixel (or -1); one predicated 16-byte load.  Callers with a run-time item index pick g with a
+    // select chain over the register array: a load under a per-item branch would make hipcc wait vmcnt(0) per item.
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int c = ch * ROWF + (hslot << 2);
-        const int g = gpix[k];
         if (g >= 0 && c < Ctot) {
             const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
             v = *reinterpret_cast<const f32x4*>(src);
         }
         return v;
     };
+    auto load_halo_item = [&](int k, int ch) -> f32x4 { return load_halo_pixel(gpix[k], ch); };
     auto store_halo_item = [&](int k, int buf, f32x4 v) {
         const int hp = hrow0 + k * (NT / SPR);
         if (hp < HP) {
@@ -197,17 +199,16 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
         if constexpr (TAPS == 9) {
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
-                f32x4 ph = {0.f, 0.f, 0.f, 0.f};
-                if (halo_next) {
+                int gsel = gpix[0];
 #pragma unroll
-                    for (int k = 0; k < MAXHI; ++k)
-                        if (k == tap) ph = load_halo_item(k, ch + 1);
-                }
+                for (int k = 1; k < MAXHI; ++k) gsel = (k == tap) ? gpix[k] : gsel;
+                const f32x4 ph = load_halo_pixel(halo_next ? gsel : -1, ch + 1);
                 const int dy = tap / 3;
                 const int tapoff = dy * HW + (tap - dy * 3);
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc) {
-                    advance_b();
+                    advance_b();                               // fragments of the NEXT k-step: a full step of flight
+                    __builtin_amdgcn_sched_barrier(0);         // keep the loads in front of this step's MFMAs
                     const int slot = (kc << 1) | lh;
                     f32x4 a[TM];
 #pragma unroll
@@ -225,11 +226,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
                 }
-                if (halo_next) {
-#pragma unroll
-                    for (int k = 0; k < MAXHI; ++k)
-                        if (k == tap) store_halo_item(k, (ch + 1) & 1, ph);
-                }
+                if (halo_next) store_halo_item(tap, (ch + 1) & 1, ph);
             }
         } else {
 #pragma unroll
@@ -241,6 +238,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
                         f32x4 ph = {0.f, 0.f, 0.f, 0.f};
                         if (item < MAXHI && halo_next) ph = load_halo_item(item < MAXHI ? item : 0, ch + 1);
                         advance_b();
+                        __builtin_amdgcn_sched_barrier(0);
                         const int slot = (sub << 3) | (kc << 1) | lh;
                         f32x4 a[TM];
 #pragma unroll

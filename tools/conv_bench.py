@@ -14,14 +14,16 @@ lib = _hip.load()
 dev = 'cuda'
 torch.manual_seed(0)
 x = torch.randn(NI * H * W * C, device=dev)
-w = torch.randn(ks * ks * N * C, device=dev) * 0.02
+w0 = torch.randn(N, C, ks, ks, device=dev) * 0.02
+w = torch.empty(lib.nd_conv_weight_floats(N, C, ks), device=dev)
+assert lib.nd_repack_conv_weight(w0.data_ptr(), w.data_ptr(), N, C, ks, torch.cuda.current_stream().cuda_stream) == 0
 b = torch.randn(N, device=dev)
 out = torch.empty(NI * H * W * N, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 fl = 2.0 * NI * H * W * N * ks * ks * C
 for v in variants:
     def run():
-        rc = lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), C, b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
+        rc = lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
                               NI, H, W, N, ks, 0, v, st)
         assert rc == 0, _hip.last_error()
     try:
