@@ -25,6 +25,15 @@
 //               tiles (blocks resident on one XCD stream the same weight fragments through that XCD's L2).
 #include "nd_common.h"
 
+#ifndef ND_SETPRIO
+#define ND_SETPRIO 0
+#endif
+#if ND_SETPRIO
+#define ND_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ND_PRIO(x)
+#endif
+
 namespace nd {
 
 struct ConvArgs {
@@ -170,12 +179,12 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    f32x4 b_cur[TN], b_nxt[TN];
+    f32x4 a_pp[2][TM], b_pp[2][TN];      // ping-pong operand registers: [k-step parity]
     // the packed buffer carries one zero c32 block of padding at the end, so the stream may always run one ahead
-    auto advance_b = [&]() {
+    auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            b_nxt[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+            dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
             bp[ni] += 256;
         }
         if (++ld_in_c32 == STEPS) {
@@ -188,15 +197,20 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     // ---- prologue: chunk 0 halo, first B fragments
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_item(k, 0));
-    advance_b();
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
+    advance_b(b_pp[0]);
     __syncthreads();
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
         const bool halo_next = (ch + 1) < nchunks;
         if constexpr (TAPS == 9) {
+            // A and B fragments are fetched one k-step ahead into the other half of a ping-pong register pair
+            // (4 k-steps per tap = even, so the roles are compile-time constants and no copies are needed).
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int hp = a_hp[mi];
+                a_pp[0][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
+            }
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 int gsel = gpix[0];
@@ -205,89 +219,115 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
                 const f32x4 ph = load_halo_pixel(halo_next ? gsel : -1, ch + 1);
                 const int dy = tap / 3;
                 const int tapoff = dy * HW + (tap - dy * 3);
+                const int ntap = tap + 1;
+                const int ndy = ntap / 3;
+                const int tapoff_n = (ntap < 9) ? ndy * HW + (ntap - ndy * 3) : 0;
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc) {
-                    advance_b();                               // fragments of the NEXT k-step: a full step of flight
-                    __builtin_amdgcn_sched_barrier(0);         // keep the loads in front of this step's MFMAs
-                    const int slot = (kc << 1) | lh;
-                    f32x4 a[TM];
+                    const int cur = kc & 1, nxt = cur ^ 1;
+                    advance_b(b_pp[nxt]);                      // fragments of the NEXT k-step: a full step of flight
+                    {
+                        const int nslot = (((kc + 1) & 3) << 1) | lh;
+                        const int noff = (kc == 3) ? tapoff_n : tapoff;
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-                        const int hp = a_hp[mi] + tapoff;
-                        a[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
+                        for (int mi = 0; mi < TM; ++mi) {
+                            const int hp = a_hp[mi] + noff;     // (after the last step of a chunk this reads stale but
+                            a_pp[nxt][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
+                        }                                       //  in-bounds data that is discarded)
                     }
+                    __builtin_amdgcn_sched_barrier(0);         // keep the loads in front of this step's MFMAs
+                    ND_PRIO(1);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < TN; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[cur][ni][j], acc[mi][ni], 0, 0, 0);
+                    ND_PRIO(0);
                 }
                 if (halo_next) store_halo_item(tap, (ch + 1) & 1, ph);
             }
         } else {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int hp = a_hp[mi];
+                a_pp[0][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
+            }
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 if (ch * NSUB + sub < p.NC32) {
 #pragma unroll
                     for (int kc = 0; kc < 4; ++kc) {
                         const int item = sub * 4 + kc;
+                        const int cur = kc & 1, nxt = cur ^ 1;
                         f32x4 ph = {0.f, 0.f, 0.f, 0.f};
                         if (item < MAXHI && halo_next) ph = load_halo_item(item < MAXHI ? item : 0, ch + 1);
-                        advance_b();
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int slot = (sub << 3) | (kc << 1) | lh;
-                        f32x4 a[TM];
+                        advance_b(b_pp[nxt]);
+                        {
+                            const int nstep = (item + 1) & (NSUB * 4 - 1);      // wraps to 0 after the last step: discarded
+                            const int nslot = (nstep << 1) | lh;
 #pragma unroll
-                        for (int mi = 0; mi < TM; ++mi) {
-                            const int hp = a_hp[mi];
-                            a[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
+                            for (int mi = 0; mi < TM; ++mi) {
+                                const int hp = a_hp[mi];
+                                a_pp[nxt][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        ND_PRIO(1);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
                             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                                 for (int ni = 0; ni < TN; ++ni)
-                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b_cur[ni][j], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni) b_cur[ni] = b_nxt[ni];
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[cur][ni][j], acc[mi][ni], 0, 0, 0);
+                        ND_PRIO(0);
                         if (item < MAXHI && halo_next) store_halo_item(item < MAXHI ? item : 0, (ch + 1) & 1, ph);
                     }
                 }
             }
         }
-        __syncthreads();
+        // halo hand-over: only LDS traffic has to be complete; the B prefetch stays in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float bv[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int n = n0 + (wn * TN + ni) * 32 + l31;
-        const bool nok = n < p.N;
-        const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+        bv[ni] = (n < p.N && p.bias) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+    for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int li = m >> (p.thl + p.twl);
-                const int oy = oy0 + ((m >> p.twl) & (TH - 1));
-                const int ox = ox0 + (m & (TW - 1));
-                const int img = img0 + li;
-                if (nok && img < p.NI && oy < p.H && ox < p.W) {
-                    float v = acc[mi][ni][e] + bv;
-                    if (p.rowbias) v += p.rowbias[(size_t)img * p.ld_rowbias + n];
-                    if (p.res) {
-                        const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                   : ((size_t)(img * p.H + oy) * p.W + ox);
-                        v += p.res[rp * p.ldr + n];
+        for (int e = 0; e < 16; ++e) {
+            const int m = (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int li = m >> (p.thl + p.twl);
+            const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+            const int ox = ox0 + (m & (TW - 1));
+            const int img = img0 + li;
+            if (img < p.NI && oy < p.H && ox < p.W) {
+                float* orow = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo;
+                const float* rb = p.rowbias ? p.rowbias + (size_t)img * p.ld_rowbias : nullptr;
+                const float* rr = nullptr;
+                if (p.res) {
+                    const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                               : ((size_t)(img * p.H + oy) * p.W + ox);
+                    rr = p.res + rp * p.ldr;
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int n = n0 + (wn * TN + ni) * 32 + l31;
+                    if (n < p.N) {
+                        float v = acc[mi][ni][e] + bv[ni];
+                        if (rb) v += rb[n];
+                        if (rr) v += rr[n];
+                        if (p.silu_out) v = fast_silu(v);
+                        orow[n] = v;
                     }
-                    if (p.silu_out) v = fast_silu(v);
-                    p.out[((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + n] = v;
                 }
             }
         }

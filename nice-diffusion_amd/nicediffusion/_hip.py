@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libnd_hip.so')
+_LIB_PATH = os.environ.get('ND_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libnd_hip.so')
 
 # flags (mirror include/nd_hip.h)
 CONV_IN_UP2X = 1
