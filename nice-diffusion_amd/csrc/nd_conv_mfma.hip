@@ -179,14 +179,20 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    f32x4 a_pp[2][TM], b_pp[2][TN];      // ping-pong operand registers: [k-step parity]
+    // operand registers: A ping-pong by k-step parity; B ring of 4 (one per k-step of a tap), fetched BDIST steps ahead
+    constexpr int BDIST = (TAPS == 9) ? 1 : 3;     // measured: deeper prefetch only pays for the short-K 1x1 form
+    f32x4 a_pp[2][TM], b_pp[4][TN];
     // the packed buffer carries one zero c32 block of padding at the end, so the stream may always run one ahead
     auto advance_b = [&](f32x4 (&dst)[TN]) {
+#if defined(ND_ABL_NOB)
+        (void)dst;     // timing-only ablation: B operands stay whatever the registers hold
+#else
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
             bp[ni] += 256;
         }
+#endif
         if (++ld_in_c32 == STEPS) {
             ld_in_c32 = 0;
 #pragma unroll
@@ -197,7 +203,8 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     // ---- prologue: chunk 0 halo, first B fragments
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_item(k, 0));
-    advance_b(b_pp[0]);
+#pragma unroll
+    for (int d = 0; d < BDIST; ++d) advance_b(b_pp[d]);
     __syncthreads();
 
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -212,41 +219,70 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
                 a_pp[0][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
             }
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                int gsel = gpix[0];
+            for (int dy = 0; dy < 3; ++dy) {
+                // Next chunk's halo arrives in 3 batches of 3 items (one batch per tap row).  vmcnt retires in order,
+                // so every wait for a B fragment also waits for any older halo load (often an HBM miss): batching
+                // exposes that latency 3x per chunk instead of 9x, and the batch is issued behind the B loads of
+                // its step so that it has two k-steps of flight before anything younger is waited for.
+                int gs[3];
 #pragma unroll
-                for (int k = 1; k < MAXHI; ++k) gsel = (k == tap) ? gpix[k] : gsel;
-                const f32x4 ph = load_halo_pixel(halo_next ? gsel : -1, ch + 1);
-                const int dy = tap / 3;
-                const int tapoff = dy * HW + (tap - dy * 3);
-                const int ntap = tap + 1;
-                const int ndy = ntap / 3;
-                const int tapoff_n = (ntap < 9) ? ndy * HW + (ntap - ndy * 3) : 0;
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    const int cur = kc & 1, nxt = cur ^ 1;
-                    advance_b(b_pp[nxt]);                      // fragments of the NEXT k-step: a full step of flight
-                    {
-                        const int nslot = (((kc + 1) & 3) << 1) | lh;
-                        const int noff = (kc == 3) ? tapoff_n : tapoff;
-#pragma unroll
-                        for (int mi = 0; mi < TM; ++mi) {
-                            const int hp = a_hp[mi] + noff;     // (after the last step of a chunk this reads stale but
-                            a_pp[nxt][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
-                        }                                       //  in-bounds data that is discarded)
-                    }
-                    __builtin_amdgcn_sched_barrier(0);         // keep the loads in front of this step's MFMAs
-                    ND_PRIO(1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < TN; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[cur][ni][j], acc[mi][ni], 0, 0, 0);
-                    ND_PRIO(0);
+                for (int i = 0; i < 3; ++i) {
+                    int g = gpix[i];
+                    g = (dy == 1) ? gpix[3 + i] : g;
+                    g = (dy == 2) ? gpix[6 + i] : g;
+                    gs[i] = halo_next ? g : -1;
                 }
-                if (halo_next) store_halo_item(tap, (ch + 1) & 1, ph);
+                f32x4 phb[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tapoff = dy * HW + dx;
+                    const int tapoff_n = (dx < 2) ? tapoff + 1 : ((dy < 2) ? (dy + 1) * HW : 0);
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const int cur = kc & 1, nxt = cur ^ 1;
+                        advance_b(b_pp[(kc + BDIST) & 3]);          // fragments BDIST k-steps ahead
+                        if (dx == 0 && kc == 0) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+#if defined(ND_ABL_NOHALO)
+                                phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                asm volatile("" :: "v"(gs[i]));
+#else
+                                phb[i] = load_halo_pixel(gs[i], ch + 1);
+#endif
+                            }
+                        }
+                        {
+                            const int nslot = (((kc + 1) & 3) << 1) | lh;
+                            const int noff = (kc == 3) ? tapoff_n : tapoff;
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi) {
+                                const int hp = a_hp[mi] + noff;     // (after the last step of a chunk this reads stale but
+#if !defined(ND_ABL_NOA)
+                                a_pp[nxt][mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
+#else
+                                asm volatile("" :: "v"(hp));
+#endif
+                            }                                       //  in-bounds data that is discarded)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);         // keep the loads in front of this step's MFMAs
+                        ND_PRIO(1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < TN; ++ni)
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[kc][ni][j], acc[mi][ni], 0, 0, 0);
+                        ND_PRIO(0);
+                    }
+                }
+#if !defined(ND_ABL_NOHALO)
+                if (halo_next) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) store_halo_item(dy * 3 + i, (ch + 1) & 1, phb[i]);
+                }
+#endif
             }
         } else {
 #pragma unroll
@@ -263,7 +299,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
                         const int cur = kc & 1, nxt = cur ^ 1;
                         f32x4 ph = {0.f, 0.f, 0.f, 0.f};
                         if (item < MAXHI && halo_next) ph = load_halo_item(item < MAXHI ? item : 0, ch + 1);
-                        advance_b(b_pp[nxt]);
+                        advance_b(b_pp[(kc + BDIST) & 3]);
                         {
                             const int nstep = (item + 1) & (NSUB * 4 - 1);      // wraps to 0 after the last step: discarded
                             const int nslot = (nstep << 1) | lh;
@@ -281,7 +317,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
                             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                                 for (int ni = 0; ni < TN; ++ni)
-                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[cur][ni][j], acc[mi][ni], 0, 0, 0);
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_pp[cur][mi][j], b_pp[kc][ni][j], acc[mi][ni], 0, 0, 0);
                         ND_PRIO(0);
                         if (item < MAXHI && halo_next) store_halo_item(item < MAXHI ? item : 0, (ch + 1) & 1, ph);
                     }
