@@ -81,6 +81,18 @@ int nd_conv_num_variants(void);
 int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias);
 int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);
 
+/* Winograd F(2x2,3x3) form of the same 3x3 stride-1 pad-1 convolution (2.25x fewer matrix instructions; fp32
+ * throughout, the transforms only use 0, +-1, +-1/2).  Same arguments and fused options as nd_conv_nhwc with ksize 3;
+ * H and W must be even; `w` must come from nd_repack_conv_weight_winograd (nd_conv_winograd_weight_floats floats);
+ * `variant` in [0, nd_conv_winograd_num_variants()).  Callers pick direct vs Winograd per shape by measurement. */
+int nd_conv_winograd_num_variants(void);
+int64_t nd_conv_winograd_weight_floats(int N, int C);
+int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream);
+int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                             const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                             const float* residual, int ldr, float* out, int ldo,
+                             int NI, int H, int W, int N, int flags, int variant, nd_stream_t stream);
+
 /* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
  * (Downsample with_conv, model.py:103-105).  Weights in PyTorch's own OIHW layout.  out is [NI, Ho, Wo, N]. */
 int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, const float* bias,

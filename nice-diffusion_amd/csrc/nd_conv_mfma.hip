@@ -391,6 +391,504 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the 3x3 convolution: 16 multiplies per 2x2 output block instead of 36, i.e. 2.25x
+// fewer MFMAs than the direct form above for the same result (Y = A^T [ (G g G^T) .* (B^T d B) ] A, all fp32;
+// the transform matrices only hold 0, +-1, +-1/2, so the rounding error stays within a few ulp of the direct sum).
+//   * the weights are transformed once at pack time (U = G g G^T) and stored in fragment order
+//     [c32][n tile][kc][position 16][lane][4];
+//   * the input transform V = B^T d B is computed on the fly from the SAME LDS halo tile the direct kernel stages
+//     (16 ds_read_b128 + 32 vector adds per lane and k-step, no extra HBM pass);
+//   * one wave owns 32 Winograd tiles (= 128 output pixels) x 32 output channels and keeps all 16 transform
+//     positions in 256 accumulator registers (one wave per SIMD, 512-register budget), so the output transform
+//     A^T M A happens in registers in the epilogue: nothing but the final NHWC result is written.
+template <int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64, 1)
+    conv_wino_kernel(const ConvArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BN = WN * 32;
+    constexpr int ROWF = 32, SPR = 8;
+    constexpr int FRAGS = 64;                       // B fragments per 32-channel chunk: 4 k-steps x 16 positions
+    constexpr int MAXHI = 12;                       // halo float4 items per thread per chunk (3 per k-step)
+    constexpr int BR = 8;                           // B fragment ring (prefetch distance BR-1 fragments)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nblk = idp / p.mt;
+    const int mblk = idp - nblk * p.mt;
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;     // output pixels per block region (both even)
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    const int hslot = tid & 7;
+    const int hrow0 = tid >> 3;
+    int gpix[MAXHI];
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) {
+        const int hp = hrow0 + k * (NT / SPR);
+        int g = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpix[k] = g;
+    }
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = p.NC32;
+
+    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int c = ch * ROWF + (hslot << 2);
+        if (g >= 0 && c < Ctot) {
+            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        return v;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v) {
+        const int hp = hrow0 + k * (NT / SPR);
+        if (hp < HP) {
+            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    };
+
+    // this lane's Winograd tile (row of the MFMA A operand): tile index -> (image, tile y, tile x) -> halo pixel of
+    // the top-left corner of its 4x4 input patch
+    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
+    const int t = wm * 32 + l31;
+    const int t_li = t >> (thl2 + twl2);
+    const int t_y = (t >> twl2) & ((1 << thl2) - 1);
+    const int t_x = t & ((1 << twl2) - 1);
+    const int a_hp0 = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
+
+    int ntile = nblk * WN + wn;
+    if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
+    const float* bp = p.w + (size_t)ntile * (FRAGS * 256) + lane * 4;
+    const size_t c32_jump = (size_t)(p.NT32 - 1) * (FRAGS * 256);
+    int ld_in_c32 = 0;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ps][e] = 0.f;
+
+    f32x4 bring[BR];
+    auto advance_b = [&](f32x4& dst) {
+#if !defined(ND_WABL_NOB)
+        dst = *reinterpret_cast<const f32x4*>(bp);
+#endif
+        bp += 256;
+        if (++ld_in_c32 == FRAGS) {
+            ld_in_c32 = 0;
+            bp += c32_jump;
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
+#pragma unroll
+    for (int d = 0; d < BR - 1; ++d) advance_b(bring[d]);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            // next chunk's halo: 3 items per k-step, issued here and parked in LDS at the end of the step
+            f32x4 phb[3];
+#pragma unroll
+#if !defined(ND_WABL_NOHALO)
+            for (int i = 0; i < 3; ++i) phb[i] = load_halo_pixel(halo_next ? gpix[kc * 3 + i] : -1, ch + 1);
+#else
+            for (int i = 0; i < 3; ++i) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+
+            // ---- input transform of this lane's tile for channels 8kc + 4lh + {0..3}
+            const int slot = (kc << 1) | lh;
+            f32x4 tr[4][4];       // after pass 1: tr[xi][j] = (B^T d)[xi][j]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hp = a_hp0 + i * HW + j;
+#if !defined(ND_WABL_NOA)
+                    d[i] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
+#else
+                    d[i] = f32x4{(float)hp, 1.f, 2.f, 3.f};
+#endif
+                }
+                tr[0][j] = d[0] - d[2];
+                tr[1][j] = d[1] + d[2];
+                tr[2][j] = d[2] - d[1];
+                tr[3][j] = d[1] - d[3];
+            }
+            // ---- 16 positions: V[xi][nu] from tr[xi][.], one B fragment and 4 MFMAs each
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                f32x4 v[4];
+                v[0] = tr[xi][0] - tr[xi][2];
+                v[1] = tr[xi][1] + tr[xi][2];
+                v[2] = tr[xi][2] - tr[xi][1];
+                v[3] = tr[xi][1] - tr[xi][3];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    const int ps = xi * 4 + nu;
+                    advance_b(bring[(ps + BR - 1) % BR]);          // fragment BR-1 positions ahead
+                    const f32x4 b = bring[ps % BR];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ps] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], b[j], acc[ps], 0, 0, 0);
+                }
+            }
+            if (halo_next) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) store_halo_item(kc * 3 + i, (ch + 1) & 1, phb[i]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: output transform Y = A^T M A per accumulator element, then bias / residual / store
+    const int n = n0 + wn * 32 + l31;
+    const bool nok = n < p.N;
+    const float bvv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float y[2][2];
+        {
+            float tm[2][4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                tm[0][nu] = acc[0 + nu][e] + acc[4 + nu][e] + acc[8 + nu][e];
+                tm[1][nu] = acc[4 + nu][e] - acc[8 + nu][e] - acc[12 + nu][e];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                y[a][0] = tm[a][0] + tm[a][1] + tm[a][2];
+                y[a][1] = tm[a][1] - tm[a][2] - tm[a][3];
+            }
+        }
+        const int te = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;       // tile of this accumulator row
+        const int li = te >> (thl2 + twl2);
+        const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+        const int txx = te & ((1 << twl2) - 1);
+        const int img = img0 + li;
+        if (nok && img < p.NI) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
+                    if (oy < p.H && ox < p.W) {
+                        float v = y[a][b2] + bvv;
+                        if (p.rowbias) v += p.rowbias[(size_t)img * p.ld_rowbias + n];
+                        if (p.res) {
+                            const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                       : ((size_t)(img * p.H + oy) * p.W + ox);
+                            v += p.res[rp * p.ldr + n];
+                        }
+                        if (p.silu_out) v = fast_silu(v);
+                        p.out[((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Second Winograd form: the 16 transform positions are split over 4 waves by row xi of the 4x4 transform (wave
+// w: xi = w & 3, n tile = w >> 2; 8 waves = 2 waves per SIMD), each wave owning TMW x 32 tiles x 32 channels x the 4
+// positions (xi, nu = 0..3) = TMW*64 accumulator registers.  Per B fragment it issues TMW*4 MFMAs (twice the reuse of
+// the form above at TMW = 2), reads only the two patch rows its xi needs, and two waves per SIMD hide each other's
+// LDS / L2 latency.  The output transform needs all four xi: Y[a][b] = sum_xi At[a][xi] * r_xi[b] with
+// r_xi[b] = sum_nu At[b][nu] M[xi][nu] computed in registers and exchanged once through LDS in the epilogue.
+template <int TMW>
+__global__ void __launch_bounds__(512, 2)
+    conv_wino2_kernel(const ConvArgs p) {
+    constexpr int NT = 512;
+    constexpr int BN = 64;
+    constexpr int ROWF = 32, SPR = 8;
+    constexpr int FRAGS = 64;
+    constexpr int MAXHI = 6;                        // halo float4 items per thread per chunk (two batches of 3)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][32]; reused by the epilogue exchange
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xi = wave & 3;
+    const int wn = wave >> 2;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nblk = idp / p.mt;
+    const int mblk = idp - nblk * p.mt;
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    const int hslot = tid & 7;
+    const int hrow0 = tid >> 3;
+    int gpix[MAXHI];
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) {
+        const int hp = hrow0 + k * (NT / SPR);
+        int g = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpix[k] = g;
+    }
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = p.NC32;
+
+    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int c = ch * ROWF + (hslot << 2);
+        if (g >= 0 && c < Ctot) {
+            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        return v;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v) {
+        const int hp = hrow0 + k * (NT / SPR);
+        if (hp < HP) {
+            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    };
+
+    // (B^T d)[xi][j] = d[ra][j] + sgn * d[rb][j]:  xi=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
+    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
+    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
+    const float sgn = (xi == 1) ? 1.f : -1.f;
+
+    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
+    // LDS float offsets (k-step 0) of the 2 x 4 patch entries this lane reads per M tile; k-step kc is offset ^ (kc << 3)
+    // because the slot index (kc << 1 | lh) only differs in bits 1-2 and the swizzle is an XOR
+    int off_a[TMW][4], off_b[TMW][4];
+#pragma unroll
+    for (int mt = 0; mt < TMW; ++mt) {
+        const int t = mt * 32 + l31;
+        const int t_li = t >> (thl2 + twl2);
+        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
+        const int t_x = t & ((1 << twl2) - 1);
+        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ha = base + ra * HW + j, hb = base + rb * HW + j;
+            off_a[mt][j] = ha * ROWF + ((lh ^ swz(ha)) << 2);
+            off_b[mt][j] = hb * ROWF + ((lh ^ swz(hb)) << 2);
+        }
+    }
+
+    int ntile = nblk * 2 + wn;
+    if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
+    // this wave's 4 fragments of k-step kc: positions 4*xi .. 4*xi+3 -> contiguous 4 KiB
+    const float* bp = p.w + ((size_t)ntile * FRAGS + 4 * xi) * 256 + lane * 4;
+    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
+
+    f32x16 acc[TMW][4];
+#pragma unroll
+    for (int mt = 0; mt < TMW; ++mt)
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nu][e] = 0.f;
+
+    f32x4 bfr[2][4];      // [k-step parity][nu]
+    auto load_b = [&](f32x4 (&dst)[4], int ch, int kc) {
+        const float* q = bp + (size_t)ch * c32_stride + kc * (16 * 256);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = *reinterpret_cast<const f32x4*>(q + nu * 256);
+    };
+
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
+    load_b(bfr[0], 0, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+        f32x4 phb[3];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int cur = kc & 1, nxt = cur ^ 1;
+            // B fragments of the next k-step (the stream has a zero block of padding at the end)
+            if (kc < 3) load_b(bfr[nxt], ch, kc + 1); else load_b(bfr[nxt], ch + 1, 0);
+            if ((kc & 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) phb[i] = load_halo_pixel(halo_next ? gpix[(kc >> 1) * 3 + i] : -1, ch + 1);
+            }
+            int kx = kc << 3;
+            asm volatile("" : "+s"(kx));          // keep the 16 x 4 per-step addresses from being hoisted into registers
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < TMW; ++mt) {
+                f32x4 v[4];
+                {
+                    f32x4 tr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 da = *reinterpret_cast<const f32x4*>(hbuf + (off_a[mt][j] ^ kx));
+                        const f32x4 db = *reinterpret_cast<const f32x4*>(hbuf + (off_b[mt][j] ^ kx));
+                        tr[j] = da + sgn * db;
+                    }
+                    v[0] = tr[0] - tr[2];
+                    v[1] = tr[1] + tr[2];
+                    v[2] = tr[2] - tr[1];
+                    v[3] = tr[1] - tr[3];
+                }
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], bfr[cur][nu][j], acc[mt][nu], 0, 0, 0);
+            }
+            if ((kc & 1) == 1 && halo_next) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) store_halo_item((kc >> 1) * 3 + i, (ch + 1) & 1, phb[i]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue.  r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS:
+    //      ex[((wn*4 + xi)*2 + b)*16 + e][lane]; then wave xi finishes accumulator rows e = 4*xi .. 4*xi+3.
+    float* ex = smem;
+    const int n = n0 + wn * 32 + l31;
+    const bool nok = n < p.N;
+    const float bvv = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < TMW; ++mt) {
+        __syncthreads();        // halo / previous round fully consumed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float r0 = acc[mt][0][e] + acc[mt][1][e] + acc[mt][2][e];
+            const float r1 = acc[mt][1][e] - acc[mt][2][e] - acc[mt][3][e];
+            ex[(((wn * 4 + xi) * 2 + 0) * 16 + e) * 64 + lane] = r0;
+            ex[(((wn * 4 + xi) * 2 + 1) * 16 + e) * 64 + lane] = r1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 4 * xi + ee;
+            float rr[4][2];
+#pragma unroll
+            for (int x2 = 0; x2 < 4; ++x2)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) rr[x2][b2] = ex[(((wn * 4 + x2) * 2 + b2) * 16 + e) * 64 + lane];
+            const int te = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int li = te >> (thl2 + twl2);
+            const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+            const int txx = te & ((1 << twl2) - 1);
+            const int img = img0 + li;
+            if (nok && img < p.NI) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const float yv = (a == 0) ? (rr[0][b2] + rr[1][b2] + rr[2][b2]) : (rr[1][b2] - rr[2][b2] - rr[3][b2]);
+                        const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
+                        if (oy < p.H && ox < p.W) {
+                            float v2 = yv + bvv;
+                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + n];
+                            if (p.res) {
+                                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                           : ((size_t)(img * p.H + oy) * p.W + ox);
+                                v2 += p.res[rp * p.ldr + n];
+                            }
+                            if (p.silu_out) v2 = fast_silu(v2);
+                            p.out[((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + n] = v2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
+__global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(it & 3);
+        const int lane = (int)((it >> 2) & 63);
+        long r = it >> 8;
+        const int ps = (int)(r & 15);
+        r >>= 4;
+        const int kc = (int)(r & 3);
+        r >>= 2;
+        const int ntile = (int)(r % NT32);
+        const int c32 = (int)(r / NT32);
+        const int n = ntile * 32 + (lane & 31);
+        const int c = c32 * 32 + kc * 8 + (lane >> 5) * 4 + j;
+        float u = 0.f;
+        if (n < N && c < C) {
+            const float* g = w + ((size_t)n * C + c) * 9;
+            const int xi = ps >> 2, nu = ps & 3;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) u += G[xi][a] * g[a * 3 + b] * G[nu][b];
+        }
+        out[it] = u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side: tile-shape variants and launch
 // ------------------------------------------------------------------------------------------------------------
 struct Variant {
@@ -627,4 +1125,131 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
     if (bn) *bn = kVariants[variant].bn();
     if (threads) *threads = kVariants[variant].nt();
     return ND_OK;
+}
+
+// ---- Winograd F(2x2,3x3) entry points -------------------------------------------------------------------------
+namespace nd {
+static const int kWinoVariants[][2] = {{2, 2}, {1, 4}, {2, 1}, {1, 2}, {2, 2}, {1, 2}};   // (M tiles, N tiles) per block
+static constexpr int kNumWino = 6;     // 0-3: one wave holds all 16 positions; 4-5: positions split over 4 waves
+
+template <int TMW>
+static int launch_wino2(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_wino2_kernel<TMW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return ND_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    return check_launch("nd_conv3x3_winograd_nhwc");
+}
+
+template <int WM, int WN>
+static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_wino_kernel<WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return ND_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    return check_launch("nd_conv3x3_winograd_nhwc");
+}
+}  // namespace nd
+
+extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
+
+extern "C" int64_t nd_conv_winograd_weight_floats(int N, int C) {
+    if (N <= 0 || C <= 0) return ND_E_ARG;
+    return (int64_t)((C + 31) / 32 + 1) * ((N + 31) / 32) * 64 * 256;
+}
+
+extern "C" int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream) {
+    const char* fn = "nd_repack_conv_weight_winograd";
+    ND_REQUIRE(w_oihw && w_out && N > 0 && C > 0, fn, "bad arguments");
+    const long total = (long)nd_conv_winograd_weight_floats(N, C);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_oihw,
+                       w_out, N, C, (N + 31) / 32, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                        const float* residual, int ldr, float* out, int ldo,
+                                        int NI, int H, int W, int N, int flags, int variant, nd_stream_t stream) {
+    const char* fn = "nd_conv3x3_winograd_nhwc";
+    ND_REQUIRE(x0 && w && out, fn, "null pointer");
+    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
+    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "Winograd F(2x2,3x3) needs even H and W");
+    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && ldo >= N, fn, "channels / strides");
+    ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
+    if (C1 > 0) ND_REQUIRE(x1 != nullptr && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn, "x1");
+    if (flags & ND_CONV_SILU_OUT) ND_REQUIRE(residual == nullptr, fn, "SILU_OUT with a residual is not supported");
+    if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
+    if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
+    ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
+    ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
+    const int WM = kWinoVariants[variant][0], WN = kWinoVariants[variant][1];
+    const bool split = variant >= 4;
+    const int nt = split ? 512 : WM * WN * 64;
+    const int maxhi = split ? 6 : 12;
+    // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
+    const int bm = WM * 128;
+    const int lbm = ilog2(bm);
+    TilePlan best{};
+    bool found = false;
+    for (int twl = 1; twl <= lbm; ++twl) {
+        for (int thl = 1; thl + twl <= lbm; ++thl) {
+            const int nibl = lbm - twl - thl;
+            const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
+            const int hp = NIB * (TH + 2) * (TW + 2);
+            if ((long)hp * 8 > (long)maxhi * nt) continue;
+            if ((size_t)2 * hp * 128 > 160 * 1024) continue;
+            TilePlan t;
+            t.thl = thl; t.twl = twl; t.nibl = nibl;
+            t.tiles_x = (W + TW - 1) / TW; t.tiles_y = (H + TH - 1) / TH; t.groups = (NI + NIB - 1) / NIB;
+            t.hp = hp;
+            t.padded = (long)t.tiles_x * t.tiles_y * t.groups * bm;
+            if (!found || t.padded < best.padded || (t.padded == best.padded && t.hp < best.hp)) { best = t; found = true; }
+        }
+    }
+    if (!found) return fail_arg(fn, "no tiling fits this shape");
+    const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
+    ConvArgs a;
+    a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
+    a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
+    a.NI = NI; a.H = H; a.W = W; a.up = up; a.res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;
+    a.Hs = H >> up; a.Ws = W >> up;
+    a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
+    a.NT32 = (N + 31) / 32; a.NC32 = (C0 + C1 + 31) / 32;
+    a.thl = best.thl; a.twl = best.twl; a.nibl = best.nibl;
+    a.tiles_x = best.tiles_x; a.tiles_y = best.tiles_y;
+    a.mt = best.tiles_x * best.tiles_y * best.groups;
+    a.nt = (N + WN * 32 - 1) / (WN * 32);
+    a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
+    const int grid = a.mt * a.nt;
+    size_t lds = (size_t)2 * best.hp * 128;
+    if (split && lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (variant) {
+        case 4: return launch_wino2<2>(a, grid, lds, s);
+        case 5: return launch_wino2<1>(a, grid, lds, s);
+        case 0: return launch_wino<2, 2>(a, grid, lds, s);
+        case 1: return launch_wino<1, 4>(a, grid, lds, s);
+        case 2: return launch_wino<2, 1>(a, grid, lds, s);
+        case 3: return launch_wino<1, 2>(a, grid, lds, s);
+    }
+    return fail_arg(fn, "bad variant");
 }

@@ -32,6 +32,9 @@ SIGNATURES = {
     'nd_embedding_add_silu': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'nd_conv_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                      _i, _i, _i, _i, _i, _i, _i, _vp],
+    'nd_conv3x3_winograd_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                 _i, _i, _i, _i, _i, _i, _vp],
+    'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _vp],
     'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -53,6 +56,8 @@ _SPECIAL = {
     'nd_version': ([], _i),
     'nd_conv_num_variants': ([], _i),
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
+    'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
+    'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),
     'nd_conv_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_last_error': ([], ctypes.c_char_p),

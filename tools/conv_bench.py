@@ -21,8 +21,20 @@ b = torch.randn(N, device=dev)
 out = torch.empty(NI * H * W * N, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 fl = 2.0 * NI * H * W * N * ks * ks * C
+wino = os.environ.get('WINO') == '1'
+if wino:
+    w = torch.empty(lib.nd_conv_winograd_weight_floats(N, C), device=dev)
+    assert lib.nd_repack_conv_weight_winograd(w0.data_ptr(), w.data_ptr(), N, C, st) == 0
+    ref_out = torch.empty_like(out)
+    wd = torch.empty(lib.nd_conv_weight_floats(N, C, 3), device=dev)
+    assert lib.nd_repack_conv_weight(w0.data_ptr(), wd.data_ptr(), N, C, 3, st) == 0
+    assert lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), b.data_ptr(), None, 0, None, 0, ref_out.data_ptr(), N, NI, H, W, N, 3, 0, -1, st) == 0
 for v in variants:
     def run():
+        if wino:
+            rc = lib.nd_conv3x3_winograd_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, 0, v, st)
+            assert rc == 0, _hip.last_error()
+            return
         rc = lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
                               NI, H, W, N, ks, 0, v, st)
         assert rc == 0, _hip.last_error()
@@ -38,5 +50,7 @@ for v in variants:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    if wino:
+        print('   winograd vs direct max abs diff %.3e (ref absmax %.3f)' % ((out - ref_out).abs().max().item(), ref_out.abs().max().item()))
     print('shape', (NI, H, W, C, N, ks), 'variant', v, 'auto->%d' % lib.nd_conv_select_variant(NI, H, W, N, ks, 0, 0) if v < 0 else '',
           '%.3f ms  %.1f TFLOP/s' % (ms, fl / ms / 1e9))
