@@ -397,236 +397,8 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 //   * the weights are transformed once at pack time (U = G g G^T) and stored in fragment order
 //     [c32][n tile][kc][position 16][lane][4];
 //   * the input transform V = B^T d B is computed on the fly from the SAME LDS halo tile the direct kernel stages
-//     (16 ds_read_b128 + 32 vector adds per lane and k-step, no extra HBM pass);
-//   * one wave owns 32 Winograd tiles (= 128 output pixels) x 32 output channels and keeps all 16 transform
-//     positions in 256 accumulator registers (one wave per SIMD, 512-register budget), so the output transform
-//     A^T M A happens in registers in the epilogue: nothing but the final NHWC result is written.
-template <int WM, int WN>
-__global__ void __launch_bounds__(WM* WN * 64, 1)
-    conv_wino_kernel(const ConvArgs p) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int BN = WN * 32;
-    constexpr int ROWF = 32, SPR = 8;
-    constexpr int FRAGS = 64;                       // B fragments per 32-channel chunk: 4 k-steps x 16 positions
-    constexpr int MAXHI = 12;                       // halo float4 items per thread per chunk (3 per k-step)
-    constexpr int BR = 8;                           // B fragment ring (prefetch distance BR-1 fragments)
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][32]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave - wm * WN;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int nblk = idp / p.mt;
-    const int mblk = idp - nblk * p.mt;
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;     // output pixels per block region (both even)
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-
-    const int hslot = tid & 7;
-    const int hrow0 = tid >> 3;
-    int gpix[MAXHI];
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) {
-        const int hp = hrow0 + k * (NT / SPR);
-        int g = -1;
-        if (hp < HP) {
-            const int li = hp / HPI;
-            const int rem = hp - li * HPI;
-            const int hy = rem / HW;
-            const int hx = rem - hy * HW;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-        }
-        gpix[k] = g;
-    }
-    const int Ctot = p.C0 + p.C1;
-    const int nchunks = p.NC32;
-
-    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
-    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = ch * ROWF + (hslot << 2);
-        if (g >= 0 && c < Ctot) {
-            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
-            v = *reinterpret_cast<const f32x4*>(src);
-        }
-        return v;
-    };
-    auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        const int hp = hrow0 + k * (NT / SPR);
-        if (hp < HP) {
-            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
-            *reinterpret_cast<f32x4*>(dst) = v;
-        }
-    };
-
-    // this lane's Winograd tile (row of the MFMA A operand): tile index -> (image, tile y, tile x) -> halo pixel of
-    // the top-left corner of its 4x4 input patch
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    const int t = wm * 32 + l31;
-    const int t_li = t >> (thl2 + twl2);
-    const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-    const int t_x = t & ((1 << twl2) - 1);
-    const int a_hp0 = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-
-    int ntile = nblk * WN + wn;
-    if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
-    const float* bp = p.w + (size_t)ntile * (FRAGS * 256) + lane * 4;
-    const size_t c32_jump = (size_t)(p.NT32 - 1) * (FRAGS * 256);
-    int ld_in_c32 = 0;
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int ps = 0; ps < 16; ++ps)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[ps][e] = 0.f;
-
-    f32x4 bring[BR];
-    auto advance_b = [&](f32x4& dst) {
-#if !defined(ND_WABL_NOB)
-        dst = *reinterpret_cast<const f32x4*>(bp);
-#endif
-        bp += 256;
-        if (++ld_in_c32 == FRAGS) {
-            ld_in_c32 = 0;
-            bp += c32_jump;
-        }
-    };
-
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
-#pragma unroll
-    for (int d = 0; d < BR - 1; ++d) advance_b(bring[d]);
-    __syncthreads();
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
-        const bool halo_next = (ch + 1) < nchunks;
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            // next chunk's halo: 3 items per k-step, issued here and parked in LDS at the end of the step
-            f32x4 phb[3];
-#pragma unroll
-#if !defined(ND_WABL_NOHALO)
-            for (int i = 0; i < 3; ++i) phb[i] = load_halo_pixel(halo_next ? gpix[kc * 3 + i] : -1, ch + 1);
-#else
-            for (int i = 0; i < 3; ++i) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-
-            // ---- input transform of this lane's tile for channels 8kc + 4lh + {0..3}
-            const int slot = (kc << 1) | lh;
-            f32x4 tr[4][4];       // after pass 1: tr[xi][j] = (B^T d)[xi][j]
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 d[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int hp = a_hp0 + i * HW + j;
-#if !defined(ND_WABL_NOA)
-                    d[i] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((slot ^ swz(hp)) << 2));
-#else
-                    d[i] = f32x4{(float)hp, 1.f, 2.f, 3.f};
-#endif
-                }
-                tr[0][j] = d[0] - d[2];
-                tr[1][j] = d[1] + d[2];
-                tr[2][j] = d[2] - d[1];
-                tr[3][j] = d[1] - d[3];
-            }
-            // ---- 16 positions: V[xi][nu] from tr[xi][.], one B fragment and 4 MFMAs each
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) {
-                f32x4 v[4];
-                v[0] = tr[xi][0] - tr[xi][2];
-                v[1] = tr[xi][1] + tr[xi][2];
-                v[2] = tr[xi][2] - tr[xi][1];
-                v[3] = tr[xi][1] - tr[xi][3];
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) {
-                    const int ps = xi * 4 + nu;
-                    advance_b(bring[(ps + BR - 1) % BR]);          // fragment BR-1 positions ahead
-                    const f32x4 b = bring[ps % BR];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[ps] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], b[j], acc[ps], 0, 0, 0);
-                }
-            }
-            if (halo_next) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) store_halo_item(kc * 3 + i, (ch + 1) & 1, phb[i]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- epilogue: output transform Y = A^T M A per accumulator element, then bias / residual / store
-    const int n = n0 + wn * 32 + l31;
-    const bool nok = n < p.N;
-    const float bvv = (nok && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float y[2][2];
-        {
-            float tm[2][4];
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                tm[0][nu] = acc[0 + nu][e] + acc[4 + nu][e] + acc[8 + nu][e];
-                tm[1][nu] = acc[4 + nu][e] - acc[8 + nu][e] - acc[12 + nu][e];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                y[a][0] = tm[a][0] + tm[a][1] + tm[a][2];
-                y[a][1] = tm[a][1] - tm[a][2] - tm[a][3];
-            }
-        }
-        const int te = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;       // tile of this accumulator row
-        const int li = te >> (thl2 + twl2);
-        const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-        const int txx = te & ((1 << twl2) - 1);
-        const int img = img0 + li;
-        if (nok && img < p.NI) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
-                    if (oy < p.H && ox < p.W) {
-                        float v = y[a][b2] + bvv;
-                        if (p.rowbias) v += p.rowbias[(size_t)img * p.ld_rowbias + n];
-                        if (p.res) {
-                            const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                       : ((size_t)(img * p.H + oy) * p.W + ox);
-                            v += p.res[rp * p.ldr + n];
-                        }
-                        if (p.silu_out) v = fast_silu(v);
-                        p.out[((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + n] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Second Winograd form: the 16 transform positions are split over 4 waves by row xi of the 4x4 transform (wave
+//     (no extra HBM pass), the output transform A^T M A in the epilogue: only the final NHWC result is written.
+// The 16 transform positions are split over 4 waves by row xi of the 4x4 transform (wave
 // w: xi = w & 3, n tile = w >> 2; 8 waves = 2 waves per SIMD), each wave owning TMW x 32 tiles x 32 channels x the 4
 // positions (xi, nu = 0..3) = TMW*64 accumulator registers.  Per B fragment it issues TMW*4 MFMAs (twice the reuse of
 // the form above at TMW = 2), reads only the two patch rows its xi needs, and two waves per SIMD hide each other's
@@ -634,7 +406,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 1)
 // r_xi[b] = sum_nu At[b][nu] M[xi][nu] computed in registers and exchanged once through LDS in the epilogue.
 template <int TMW>
 __global__ void __launch_bounds__(512, 2)
-    conv_wino2_kernel(const ConvArgs p) {
+    conv_wino_kernel(const ConvArgs p) {
     constexpr int NT = 512;
     constexpr int BN = 64;
     constexpr int ROWF = 32, SPR = 8;
@@ -1129,12 +901,12 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
 
 // ---- Winograd F(2x2,3x3) entry points -------------------------------------------------------------------------
 namespace nd {
-static const int kWinoVariants[][2] = {{2, 2}, {1, 4}, {2, 1}, {1, 2}, {2, 2}, {1, 2}};   // (M tiles, N tiles) per block
-static constexpr int kNumWino = 6;     // 0-3: one wave holds all 16 positions; 4-5: positions split over 4 waves
+static const int kWinoTmw[] = {2, 1};      // M tiles (of 32 Winograd tiles = 128 output pixels) per block; BN = 64
+static constexpr int kNumWino = 2;
 
 template <int TMW>
-static int launch_wino2(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino2_kernel<TMW>;
+static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_wino_kernel<TMW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1149,22 +921,6 @@ static int launch_wino2(const ConvArgs& a, int grid, size_t lds, hipStream_t s) 
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
 
-template <int WM, int WN>
-static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino_kernel<WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
-    return check_launch("nd_conv3x3_winograd_nhwc");
-}
 }  // namespace nd
 
 extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
@@ -1201,10 +957,9 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const int WM = kWinoVariants[variant][0], WN = kWinoVariants[variant][1];
-    const bool split = variant >= 4;
-    const int nt = split ? 512 : WM * WN * 64;
-    const int maxhi = split ? 6 : 12;
+    const int WM = kWinoTmw[variant], WN = 2;
+    const int nt = 512;
+    const int maxhi = 6;
     // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
     const int bm = WM * 128;
     const int lbm = ilog2(bm);
@@ -1241,15 +996,11 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     const int grid = a.mt * a.nt;
     size_t lds = (size_t)2 * best.hp * 128;
-    if (split && lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats
+    if (lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
-        case 4: return launch_wino2<2>(a, grid, lds, s);
-        case 5: return launch_wino2<1>(a, grid, lds, s);
-        case 0: return launch_wino<2, 2>(a, grid, lds, s);
-        case 1: return launch_wino<1, 4>(a, grid, lds, s);
-        case 2: return launch_wino<2, 1>(a, grid, lds, s);
-        case 3: return launch_wino<1, 2>(a, grid, lds, s);
+        case 0: return launch_wino<2>(a, grid, lds, s);
+        case 1: return launch_wino<1>(a, grid, lds, s);
     }
     return fail_arg(fn, "bad variant");
 }

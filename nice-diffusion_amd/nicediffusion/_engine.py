@@ -136,55 +136,92 @@ class UNetPlan:
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
-    def conv(self, src, w_ptr, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
-             residual=None, flags=0, label='conv'):
-        """Emit nd_conv_nhwc.  ``src`` (and optional ``src2``) are Acts; output spatial size is src's, doubled when
-        CONV_IN_UP2X is set."""
+    def _packed_wino(self, weight, pad_c_to=None):
+        """3x3 weight -> Winograd domain (U = G g G^T) in fragment order, once, on the device."""
+        w = weight.detach().contiguous()
+        N, C = w.shape[0], w.shape[1]
+        if pad_c_to is not None and pad_c_to != C:
+            wp = torch.zeros((N, pad_c_to, 3, 3), dtype=w.dtype, device=w.device)
+            wp[:, :C] = w
+            w, C = wp, pad_c_to
+        n = self.lib.nd_conv_winograd_weight_floats(N, C)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.nd_repack_conv_weight_winograd(w.data_ptr(), out.data_ptr(), N, C, self._stream()),
+                   'nd_repack_conv_weight_winograd')
+        return out
+
+    def conv(self, src, weight, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
+             residual=None, flags=0, label='conv', pad_c_to=None):
+        """Emit one convolution.  ``src`` (and optional ``src2``, concatenated after it) are Acts; ``weight`` is the
+        module's parameter (packed here); output spatial size is src's, doubled when CONV_IN_UP2X is set.  For 3x3
+        convolutions on even sizes the Winograd F(2x2,3x3) kernel competes with the direct kernel's tile shapes and
+        the fastest measured implementation is kept."""
         up = 1 if (flags & _hip.CONV_IN_UP2X) else 0
         NI, H, W = src.NI, src.H << up, src.W << up
         if out is None:
             out = self._new(NI, H, W, N)
         C1 = 0 if src2 is None else src2.C
-        args = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld,
-                w_ptr, bias, rowbias, ld_rowbias,
-                None if residual is None else residual.ptr, 0 if residual is None else residual.ld,
-                out.ptr, out.ld, NI, H, W, N, ksize, flags, -1]
+        head = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld]
+        tail = [bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
+                0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
-        var = self._pick_variant(args, (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None,
-                                        residual is not None), fl)
-        args[-1] = var
-        self._emit(self.lib.nd_conv_nhwc, args, label, flops=fl, variant=var, ksize=ksize,
-                   shape=(NI, H, W, src.C + C1, N))
+        key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None)
+        kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags)
+        if kind == 'wino':
+            wq = self._packed_wino(weight, pad_c_to)
+            self.keep.append(wq)
+            self.packed_floats += wq.numel()
+            self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var], label, flops=fl,
+                       variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+        else:
+            wp = self._packed(weight, pad_c_to)
+            self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var], label, flops=fl,
+                       variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         return out
 
-    def _pick_variant(self, args, key, flops):
-        """Tile-shape variant for one conv launch: measured on the device (3 timed launches per candidate, best
-        kept, cached per shape) unless ND_AUTOTUNE=0, in which case the library's cost model decides."""
-        NI, H, W, C, N, ksize, flags, has_rb, _ = key
-        heur = self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0)
+    def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags):
+        """(kind, variant) for one conv launch.  Measured on the device: 3 timed launches per candidate -- every direct
+        tile shape that fits and, for 3x3 on even sizes, the Winograd variants -- best kept and cached per shape.
+        ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
+        import os
+        NI, H, W, C, N, ksize, _, has_rb, _ = key
+        heur = ('direct', self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0))
         if not _autotune_enabled() or flops < 2e8:
             return heur
         ck = (self.device.index,) + key
         if ck in _TUNED:
             return _TUNED[ck]
         stream = self._stream()
-        best, best_ms = heur, None
-        for v in range(self.lib.nd_conv_num_variants()):
-            a = list(args)
-            a[-1] = v
-            if self.lib.nd_conv_nhwc(*a, stream) != 0:
-                continue                              # this tile shape does not fit the problem
+
+        def time_it(fn, args):
+            if fn(*args, stream) != 0:
+                return None                           # this tile shape does not fit the problem
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                self.lib.nd_conv_nhwc(*a, stream)
+                fn(*args, stream)
             e1.record()
             e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if best_ms is None or ms < best_ms:
-                best, best_ms = v, ms
+            return e0.elapsed_time(e1)
+
+        best, best_ms = heur, None
+        wp = self._packed(weight, pad_c_to)
+        self.keep.pop()                               # tuning copy; the chosen kind is packed again by the caller
+        self.packed_floats -= wp.numel()
+        for v in range(self.lib.nd_conv_num_variants()):
+            ms = time_it(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v])
+            if ms is not None and (best_ms is None or ms < best_ms):
+                best, best_ms = ('direct', v), ms
+        if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
+            wq = self._packed_wino(weight, pad_c_to)
+            for v in range(self.lib.nd_conv_winograd_num_variants()):
+                ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v])
+                if ms is not None and (best_ms is None or ms < best_ms):
+                    best, best_ms = ('wino', v), ms
+            del wq
+        del wp
         _TUNED[ck] = best
         return best
 
@@ -194,7 +231,7 @@ class UNetPlan:
                 None if bias is None else bias.detach().data_ptr(),
                 None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1]
         var = self.lib.nd_conv_select_variant(1, 1, M, N, 1, flags, 0)
-        self._emit(self.lib.nd_conv_nhwc, args, label, flops=2 * M * N * K, variant=var, ksize=1)
+        self._emit(self.lib.nd_conv_nhwc, args, label, flops=2 * M * N * K, variant=('direct', var), ksize=1)
         self.flops += 2 * M * N * K
 
     def groupnorm(self, src, norm, out=None, src2=None, scale_ptr=None, shift_ptr=None, ld_ss=0, silu=True,
@@ -262,7 +299,7 @@ class UNetPlan:
             args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self._packed(self.e_w).data_ptr(), self.e_b.data_ptr(),
                     None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1]
             var = lib.nd_conv_select_variant(1, 1, NI, self.e_ld, 1, 0, 0)
-            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=var, ksize=1)
+            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=('direct', var), ksize=1)
             self.flops += 2 * NI * self.e_ld * ed
 
         # ---- the UNet proper
@@ -280,7 +317,7 @@ class UNetPlan:
         h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
         self._release(x_cur)
         out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
-        self.conv(h, self._packed(m.out[2].weight).data_ptr(), m.out[2].bias.detach().data_ptr(), self.Cout, 3,
+        self.conv(h, m.out[2].weight, m.out[2].bias.detach().data_ptr(), self.Cout, 3,
                   out=out_act, label='conv3x3')
         self._release(h)
 
@@ -311,9 +348,8 @@ class UNetPlan:
                 nxt = self._attn_block(layer, cur)
             elif isinstance(layer, torch.nn.Conv2d):
                 assert cur2 is None
-                wp = self._packed(layer.weight, pad_c_to=cur.C)
-                nxt = self.conv(cur, wp.data_ptr(), layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
-                                label='conv3x3')
+                nxt = self.conv(cur, layer.weight, layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
+                                label='conv3x3', pad_c_to=cur.C)
             elif isinstance(layer, M.Downsample):
                 assert cur2 is None
                 nxt = self._downsample(layer, cur)
@@ -340,9 +376,8 @@ class UNetPlan:
         # h = silu(in_norm(x)); 'down' pools here, 'up' is folded into the conv's input addressing
         h0 = self.groupnorm(x, rb.in_norm, src2=x2, silu=True, pool=(mode == 'down'), label='res.in_norm')
         e_ptr = self.e_all.data_ptr() + 4 * self.e_off[id(rb)]
-        wp = self._packed(rb.in_conv.weight)
         adaptive = rb.use_adaptive_gn
-        h1 = self.conv(h0, wp.data_ptr(), rb.in_conv.bias.detach().data_ptr(), Cout, 3,
+        h1 = self.conv(h0, rb.in_conv.weight, rb.in_conv.bias.detach().data_ptr(), Cout, 3,
                        rowbias=None if adaptive else e_ptr, ld_rowbias=0 if adaptive else self.e_ld,
                        flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
         self._release(h0)
@@ -364,7 +399,7 @@ class UNetPlan:
             xs, xs2 = x, x2
         if isinstance(rb.skip, torch.nn.Conv2d):
             k = rb.skip.weight.shape[-1]
-            s = self.conv(xs, self._packed(rb.skip.weight).data_ptr(), rb.skip.bias.detach().data_ptr(), Cout, k,
+            s = self.conv(xs, rb.skip.weight, rb.skip.bias.detach().data_ptr(), Cout, k,
                           src2=xs2, flags=_hip.CONV_IN_UP2X if mode == 'up' else 0,
                           label='conv1x1' if k == 1 else 'conv3x3')
             if tmp is not None:
@@ -376,8 +411,7 @@ class UNetPlan:
             res = xs
             if mode == 'up':
                 flags |= _hip.CONV_RES_UP2X
-        wp2 = self._packed(rb.out_conv.weight)
-        out = self.conv(h2, wp2.data_ptr(), rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
+        out = self.conv(h2, rb.out_conv.weight, rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
                         flags=flags, label='conv3x3')
         self._release(h2)
         if tmp is not None:
@@ -389,7 +423,7 @@ class UNetPlan:
         NI, H, W, C = x.NI, x.H, x.W, x.C
         T = H * W
         n = self.groupnorm(x, ab.norm, silu=False, label='attn.norm')
-        qkv = self.conv(n, self._packed(ab.qkv_nin.weight).data_ptr(), ab.qkv_nin.bias.detach().data_ptr(), 3 * C, 1,
+        qkv = self.conv(n, ab.qkv_nin.weight, ab.qkv_nin.bias.detach().data_ptr(), 3 * C, 1,
                         label='conv1x1')
         self._release(n)
         a = self._new(NI, H, W, C)
@@ -405,7 +439,7 @@ class UNetPlan:
         self.flops += 4 * NI * nh * T * T * hd
         self.conv_flops['attention'] = self.conv_flops.get('attention', 0) + 4 * NI * nh * T * T * hd
         self._release(qkv)
-        out = self.conv(a, self._packed(ab.proj_out.weight).data_ptr(), ab.proj_out.bias.detach().data_ptr(), C, 1,
+        out = self.conv(a, ab.proj_out.weight, ab.proj_out.bias.detach().data_ptr(), C, 1,
                         residual=x, label='conv1x1')
         self._release(a)
         return out
@@ -432,7 +466,7 @@ class UNetPlan:
         NI = x.NI
         if layer.with_conv:
             N = layer.conv.weight.shape[0]
-            return self.conv(x, self._packed(layer.conv.weight).data_ptr(), layer.conv.bias.detach().data_ptr(), N, 3,
+            return self.conv(x, layer.conv.weight, layer.conv.bias.detach().data_ptr(), N, 3,
                              flags=_hip.CONV_IN_UP2X, label='conv3x3')
         out = self._new(NI, 2 * x.H, 2 * x.W, x.C)
         self._emit(self.lib.nd_upsample2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'upsample')

@@ -92,6 +92,68 @@ def test_conv3x3_all_variants(B, Cin, Cout, H, W):
     assert ran >= 3
 
 
+def pack_wino(w):
+    N, C = w.shape[0], w.shape[1]
+    out = torch.full((lib().nd_conv_winograd_weight_floats(N, C),), float('nan'), device=DEV)
+    wd = w.contiguous().to(DEV)
+    _hip.check(lib().nd_repack_conv_weight_winograd(wd.data_ptr(), out.data_ptr(), N, C, st()))
+    return out
+
+
+WINO_CASES = [(2, 32, 32, 16, 16), (1, 64, 96, 8, 8), (3, 4, 32, 28, 28), (2, 96, 6, 16, 16), (1, 192, 192, 64, 64),
+              (2, 32, 2, 14, 14), (5, 64, 64, 4, 4), (3, 36, 40, 6, 10), (2, 64, 64, 2, 2)]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', WINO_CASES)
+def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
+    """Winograd F(2x2,3x3) form vs a plain fp32 conv2d: same tolerance as the direct form."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    xd, wd, bd = nhwc(x), pack_wino(w), b.to(DEV)
+    for v in range(lib().nd_conv_winograd_num_variants()):
+        out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, st()))
+        got = from_nhwc(out, B, H, W, Cout)
+        assert torch.isfinite(got).all(), v
+        assert (got - ref).abs().max().item() < 2e-4, (v, (got - ref).abs().max().item())
+    # odd sizes are refused (callers use the direct form)
+    rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                        out.data_ptr(), Cout, B, H - 1, W, Cout, 0, 0, st())
+    assert rc == -1 and 'even' in _hip.last_error()
+
+
+def test_conv3x3_winograd_fused_options():
+    B, C0, C1, Cout, H, W = 2, 64, 32, 64, 8, 8
+    xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, C1, H, W, seed=2)
+    w, b = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.05), rnd(Cout, seed=4)
+    rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
+    ref = F.conv2d(torch.cat([xa, xb], 1), w, b, padding=1) + rb[:, :, None, None] + res
+    wd = pack_wino(w)
+    xad, xbd, bd, rbd, resd = nhwc(xa), nhwc(xb), b.to(DEV), rb.to(DEV), nhwc(res)
+    x, r = rnd(B, C0, H, W, seed=7), rnd(B, Cout, H, W, seed=8)
+    w2 = rnd(Cout, C0, 3, 3, seed=9, scale=0.05)
+    up = lambda t: F.interpolate(t, scale_factor=2.0, mode='nearest')
+    ref2 = F.conv2d(up(x), w2, b, padding=1) + up(r)
+    wd2, xd, rd = pack_wino(w2), nhwc(x), nhwc(r)
+    ref3 = F.silu(F.conv2d(x, w2, b, padding=1))
+    for v in range(lib().nd_conv_winograd_num_variants()):
+        out = torch.empty(B * H * W * Cout, device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
+                                                  rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
+                                                  Cout, 0, v, st()))
+        assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
+        out = torch.empty(B * 4 * H * W * Cout, device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
+                                                  rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout,
+                                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, v, st()))
+        assert (from_nhwc(out, B, 2 * H, 2 * W, Cout) - ref2).abs().max().item() < 2e-4
+        out = torch.empty(B * H * W * Cout, device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
+                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, _hip.CONV_SILU_OUT, v, st()))
+        assert (from_nhwc(out, B, H, W, Cout) - ref3).abs().max().item() < 2e-4
+
+
 def test_conv3x3_fused_options():
     """two-source concat input, per-image bias, residual, nearest-2x input and residual (model.py:474,205,211,77)."""
     B, C0, C1, Cout, H, W = 2, 64, 32, 64, 8, 8
