@@ -521,8 +521,12 @@ __global__ void __launch_bounds__(512, 2)
     f32x4 bfr[2][4];      // [k-step parity][nu]
     auto load_b = [&](f32x4 (&dst)[4], int ch, int kc) {
         const float* q = bp + (size_t)ch * c32_stride + kc * (16 * 256);
+#if !defined(ND_WABL_NOB)
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) dst[nu] = *reinterpret_cast<const f32x4*>(q + nu * 256);
+#else
+        asm volatile("" :: "v"(q));
+#endif
     };
 
 #pragma unroll
@@ -541,7 +545,11 @@ __global__ void __launch_bounds__(512, 2)
             if (kc < 3) load_b(bfr[nxt], ch, kc + 1); else load_b(bfr[nxt], ch + 1, 0);
             if ((kc & 1) == 0) {
 #pragma unroll
+#if !defined(ND_WABL_NOHALO)
                 for (int i = 0; i < 3; ++i) phb[i] = load_halo_pixel(halo_next ? gpix[(kc >> 1) * 3 + i] : -1, ch + 1);
+#else
+                for (int i = 0; i < 3; ++i) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
             }
             int kx = kc << 3;
             asm volatile("" : "+s"(kx));          // keep the 16 x 4 per-step addresses from being hoisted into registers
@@ -553,8 +561,12 @@ __global__ void __launch_bounds__(512, 2)
                     f32x4 tr[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+#if !defined(ND_WABL_NOA)
                         const f32x4 da = *reinterpret_cast<const f32x4*>(hbuf + (off_a[mt][j] ^ kx));
                         const f32x4 db = *reinterpret_cast<const f32x4*>(hbuf + (off_b[mt][j] ^ kx));
+#else
+                        const f32x4 da = {(float)(off_a[mt][j] ^ kx), 1.f, 2.f, 3.f}, db = {(float)(off_b[mt][j] ^ kx), 1.f, 2.f, 3.f};
+#endif
                         tr[j] = da + sgn * db;
                     }
                     v[0] = tr[0] - tr[2];
