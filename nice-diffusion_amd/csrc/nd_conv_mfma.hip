@@ -404,14 +404,18 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 // the form above at TMW = 2), reads only the two patch rows its xi needs, and two waves per SIMD hide each other's
 // LDS / L2 latency.  The output transform needs all four xi: Y[a][b] = sum_xi At[a][xi] * r_xi[b] with
 // r_xi[b] = sum_nu At[b][nu] M[xi][nu] computed in registers and exchanged once through LDS in the epilogue.
-template <int TMW>
+// NSUB = 32-channel sub-chunks per LDS chunk (2 halves the barrier count; needs the smaller TMW = 1 halo);
+// APF = read the raw patch entries of the next k-step ahead of this step's MFMAs (TMW = 1 has the registers for it).
+template <int TMW, int NSUB, bool APF>
 __global__ void __launch_bounds__(512, 2)
     conv_wino_kernel(const ConvArgs p) {
     constexpr int NT = 512;
     constexpr int BN = 64;
-    constexpr int ROWF = 32, SPR = 8;
+    constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
     constexpr int FRAGS = 64;
     constexpr int MAXHI = 6;                        // halo float4 items per thread per chunk (two batches of 3)
+    constexpr int NSTEP = 4 * NSUB;                 // k-steps (8 channels) per chunk
+    static_assert(!APF || TMW == 1, "A prefetch is implemented for TMW = 1");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][32]; reused by the epilogue exchange
 
@@ -440,8 +444,8 @@ __global__ void __launch_bounds__(512, 2)
     const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
     const int n0 = nblk * BN;
 
-    const int hslot = tid & 7;
-    const int hrow0 = tid >> 3;
+    const int hslot = tid % SPR;
+    const int hrow0 = tid / SPR;
     int gpix[MAXHI];
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) {
@@ -460,9 +464,9 @@ __global__ void __launch_bounds__(512, 2)
         gpix[k] = g;
     }
     const int Ctot = p.C0 + p.C1;
-    const int nchunks = p.NC32;
+    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
 
-    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
+    auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
     auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int c = ch * ROWF + (hslot << 2);
@@ -519,8 +523,8 @@ __global__ void __launch_bounds__(512, 2)
             for (int e = 0; e < 16; ++e) acc[mt][nu][e] = 0.f;
 
     f32x4 bfr[2][4];      // [k-step parity][nu]
-    auto load_b = [&](f32x4 (&dst)[4], int ch, int kc) {
-        const float* q = bp + (size_t)ch * c32_stride + kc * (16 * 256);
+    auto load_b = [&](f32x4 (&dst)[4], int c32, int kc) {
+        const float* q = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
 #if !defined(ND_WABL_NOB)
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) dst[nu] = *reinterpret_cast<const f32x4*>(q + nu * 256);
@@ -528,61 +532,85 @@ __global__ void __launch_bounds__(512, 2)
         asm volatile("" :: "v"(q));
 #endif
     };
+    // raw patch entries (2 rows x 4 columns per M tile) of k-step st of the chunk staged at hbuf
+    auto read_patch = [&](const float* hbuf, int st, int mt, f32x4 (&da)[4], f32x4 (&db)[4]) {
+        int kx = st << 3;
+        asm volatile("" : "+s"(kx));          // keep the per-step addresses from being hoisted into registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#if !defined(ND_WABL_NOA)
+            da[j] = *reinterpret_cast<const f32x4*>(hbuf + (off_a[mt][j] ^ kx));
+            db[j] = *reinterpret_cast<const f32x4*>(hbuf + (off_b[mt][j] ^ kx));
+#else
+            da[j] = f32x4{(float)(off_a[mt][j] ^ kx), 1.f, 2.f, 3.f};
+            db[j] = f32x4{(float)(off_b[mt][j] ^ kx), 1.f, 2.f, 3.f};
+#endif
+        }
+    };
 
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
     load_b(bfr[0], 0, 0);
     __syncthreads();
 
+    f32x4 pa[2][4], pb[2][4];      // raw patch rows ra / rb of the A-prefetch form, [k-step parity]
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
         const bool halo_next = (ch + 1) < nchunks;
+        int nvalid = (p.NC32 - ch * NSUB) * 4;          // k-steps of this chunk that hold real channels
+        if (nvalid > NSTEP) nvalid = NSTEP;
         f32x4 phb[3];
+        if constexpr (APF) read_patch(hbuf, 0, 0, pa[0], pb[0]);
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int cur = kc & 1, nxt = cur ^ 1;
-            // B fragments of the next k-step (the stream has a zero block of padding at the end)
-            if (kc < 3) load_b(bfr[nxt], ch, kc + 1); else load_b(bfr[nxt], ch + 1, 0);
-            if ((kc & 1) == 0) {
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st < nvalid) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                // B fragments of the next k-step (the stream has a zero block of padding at the end)
+                if (st + 1 < NSTEP) load_b(bfr[nxt], ch * NSUB + ((st + 1) >> 2), (st + 1) & 3);
+                else load_b(bfr[nxt], (ch + 1) * NSUB, 0);
+                if (st == 0 || st == NSTEP / 2) {
 #pragma unroll
+                    for (int i = 0; i < 3; ++i) {
 #if !defined(ND_WABL_NOHALO)
-                for (int i = 0; i < 3; ++i) phb[i] = load_halo_pixel(halo_next ? gpix[(kc >> 1) * 3 + i] : -1, ch + 1);
+                        phb[i] = load_halo_pixel(halo_next ? gpix[(st ? 3 : 0) + i] : -1, ch + 1);
 #else
-                for (int i = 0; i < 3; ++i) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
-            }
-            int kx = kc << 3;
-            asm volatile("" : "+s"(kx));          // keep the 16 x 4 per-step addresses from being hoisted into registers
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < TMW; ++mt) {
-                f32x4 v[4];
-                {
-                    f32x4 tr[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-#if !defined(ND_WABL_NOA)
-                        const f32x4 da = *reinterpret_cast<const f32x4*>(hbuf + (off_a[mt][j] ^ kx));
-                        const f32x4 db = *reinterpret_cast<const f32x4*>(hbuf + (off_b[mt][j] ^ kx));
-#else
-                        const f32x4 da = {(float)(off_a[mt][j] ^ kx), 1.f, 2.f, 3.f}, db = {(float)(off_b[mt][j] ^ kx), 1.f, 2.f, 3.f};
-#endif
-                        tr[j] = da + sgn * db;
                     }
-                    v[0] = tr[0] - tr[2];
-                    v[1] = tr[1] + tr[2];
-                    v[2] = tr[2] - tr[1];
-                    v[3] = tr[1] - tr[3];
                 }
+                if constexpr (APF) {
+                    if (st + 1 < NSTEP) read_patch(hbuf, st + 1, 0, pa[nxt], pb[nxt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
+                for (int mt = 0; mt < TMW; ++mt) {
+                    f32x4 v[4];
+                    {
+                        f32x4 tr[4];
+                        if constexpr (APF) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], bfr[cur][nu][j], acc[mt][nu], 0, 0, 0);
-            }
-            if ((kc & 1) == 1 && halo_next) {
+                            for (int j = 0; j < 4; ++j) tr[j] = pa[cur][j] + sgn * pb[cur][j];
+                        } else {
+                            f32x4 da[4], db[4];
+                            read_patch(hbuf, st, mt, da, db);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) store_halo_item((kc >> 1) * 3 + i, (ch + 1) & 1, phb[i]);
+                            for (int j = 0; j < 4; ++j) tr[j] = da[j] + sgn * db[j];
+                        }
+                        v[0] = tr[0] - tr[2];
+                        v[1] = tr[1] + tr[2];
+                        v[2] = tr[2] - tr[1];
+                        v[3] = tr[1] - tr[3];
+                    }
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], bfr[cur][nu][j], acc[mt][nu], 0, 0, 0);
+                }
+                if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) store_halo_item((st == 1 ? 0 : 3) + i, (ch + 1) & 1, phb[i]);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -913,12 +941,13 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
 
 // ---- Winograd F(2x2,3x3) entry points -------------------------------------------------------------------------
 namespace nd {
-static const int kWinoTmw[] = {2, 1};      // M tiles (of 32 Winograd tiles = 128 output pixels) per block; BN = 64
-static constexpr int kNumWino = 2;
+// {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch}; BN = 64
+static const int kWinoCfg[][3] = {{2, 1, 0}, {1, 1, 0}, {1, 1, 1}, {1, 2, 1}, {1, 2, 0}};
+static constexpr int kNumWino = 5;
 
-template <int TMW>
+template <int TMW, int NSUB, bool APF>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino_kernel<TMW>;
+    auto kern = conv_wino_kernel<TMW, NSUB, APF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -969,7 +998,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const int WM = kWinoTmw[variant], WN = 2;
+    const int WM = kWinoCfg[variant][0], WN = 2;
+    const int nsub = kWinoCfg[variant][1];
     const int nt = 512;
     const int maxhi = 6;
     // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
@@ -982,8 +1012,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2) * (TW + 2);
-            if ((long)hp * 8 > (long)maxhi * nt) continue;
-            if ((size_t)2 * hp * 128 > 160 * 1024) continue;
+            if ((long)hp * 8 * nsub > (long)maxhi * nt) continue;
+            if ((size_t)2 * hp * 128 * nsub > 160 * 1024) continue;
             TilePlan t;
             t.thl = thl; t.twl = twl; t.nibl = nibl;
             t.tiles_x = (W + TW - 1) / TW; t.tiles_y = (H + TH - 1) / TH; t.groups = (NI + NIB - 1) / NIB;
@@ -1007,12 +1037,15 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.nt = (N + WN * 32 - 1) / (WN * 32);
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     const int grid = a.mt * a.nt;
-    size_t lds = (size_t)2 * best.hp * 128;
+    size_t lds = (size_t)2 * best.hp * 128 * nsub;
     if (lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
-        case 0: return launch_wino<2>(a, grid, lds, s);
-        case 1: return launch_wino<1>(a, grid, lds, s);
+        case 0: return launch_wino<2, 1, false>(a, grid, lds, s);
+        case 1: return launch_wino<1, 1, false>(a, grid, lds, s);
+        case 2: return launch_wino<1, 1, true>(a, grid, lds, s);
+        case 3: return launch_wino<1, 2, true>(a, grid, lds, s);
+        case 4: return launch_wino<1, 2, false>(a, grid, lds, s);
     }
     return fail_arg(fn, "bad variant");
 }
