@@ -33,6 +33,7 @@ typedef void* nd_stream_t; /* hipStream_t */
 #define ND_CONV_IN_UP2X 1   /* input is stored at half resolution and read through nearest-2x upsampling */
 #define ND_CONV_RES_UP2X 2  /* residual is stored at half resolution and read through nearest-2x upsampling */
 #define ND_CONV_SILU_OUT 4  /* apply SiLU to the result (after bias; residual must be NULL) */
+#define ND_CONV_GN_SILU 8   /* with gnA/gnB: SiLU after the fused GroupNorm affine of the INPUT */
 
 /* flags for nd_groupnorm_apply_nhwc */
 #define ND_GN_SILU 1        /* SiLU after the affine */
@@ -68,11 +69,15 @@ int nd_embedding_add_silu(float* emb, const float* table, const int64_t* y, int 
  *   w is the weight tensor over the C0+C1 concatenated input channels in MFMA-fragment order (nd_repack_conv_weight).
  *   bias [N] | NULL;  rowbias [NI][ld_rowbias] | NULL (per-image bias: the timestep embedding of model.py:205);
  *   residual [NI,H,W,N] stride ldr | NULL (model.py:211, :291).  `variant` < 0 selects the tile shape automatically.
+ *   gnA/gnB [NI][ld_gn] | NULL: GroupNorm(+AdaGN)(+SiLU with ND_CONV_GN_SILU) of the INPUT folded into the loader,
+ *   in' = act(in * gnA[img][c] + gnB[img][c]) (coefficients from nd_groupnorm_coeffs; zero padding stays zero, as
+ *   the reference pads the normalised tensor).  Needs H*W >= the pixel tile (one image per block).
  */
 int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                  const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                  const float* residual, int ldr, float* out, int ldo,
-                 int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream);
+                 int NI, int H, int W, int N, int ksize, int flags, int variant,
+                 const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream);
 
 /* Number of tile-shape variants nd_conv_nhwc accepts for `variant` (0 .. n-1). */
 int nd_conv_num_variants(void);
@@ -91,7 +96,8 @@ int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int
 int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                              const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                              const float* residual, int ldr, float* out, int ldo,
-                             int NI, int H, int W, int N, int flags, int variant, nd_stream_t stream);
+                             int NI, int H, int W, int N, int flags, int variant,
+                             const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream);
 
 /* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
  * (Downsample with_conv, model.py:103-105).  Weights in PyTorch's own OIHW layout.  out is [NI, Ho, Wo, N]. */
@@ -116,6 +122,11 @@ int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int k
 int nd_groupnorm_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, double* stats, int NI, int HW, int G,
                             nd_stream_t stream);
+/* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions
+ * that apply it while loading their input (gnA/gnB of nd_conv_nhwc / nd_conv3x3_winograd_nhwc). */
+int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
+                        const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
+                        int NI, int C, int HW, int G, float eps, nd_stream_t stream);
 int nd_groupnorm_apply_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, const double* stats,
                             const float* gamma, const float* beta,

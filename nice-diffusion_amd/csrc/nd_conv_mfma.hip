@@ -55,6 +55,10 @@ struct ConvArgs {
     int thl, twl, nibl;   // log2 of tile height / width / images per block
     int tiles_x, tiles_y, mt, nt;
     int silu_out;
+    // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
+    const float* gnA;
+    const float* gnB;
+    int ld_gn, gn_silu, gn_hw;    // gn_hw > 0: flat pixel list, image = pixel / gn_hw
 };
 
 __host__ __device__ inline int nc32_padded(int C) {
@@ -132,12 +136,31 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
     // g = source pixel (or -1); one predicated 16-byte load.  Callers with a run-time item index pick g with a
     // select chain over the register array: a load under a per-item branch would make hipcc wait vmcnt(0) per item.
+    // fused GroupNorm: this thread always loads the same 4 channels of a chunk, so one coefficient pair per chunk
+    const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
+    auto load_gn = [&](int ch, f32x4& cA, f32x4& cB) {
+        cA = f32x4{1.f, 1.f, 1.f, 1.f};
+        cB = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = ch * ROWF + (hslot << 2);
+        if (p.gnA && c < Ctot) {
+            cA = *reinterpret_cast<const f32x4*>(p.gnA + (size_t)gimg * p.ld_gn + c);
+            cB = *reinterpret_cast<const f32x4*>(p.gnB + (size_t)gimg * p.ld_gn + c);
+        }
+    };
+    f32x4 gA, gB;            // coefficients of the chunk whose halo is being fetched
     auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int c = ch * ROWF + (hslot << 2);
         if (g >= 0 && c < Ctot) {
             const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
             v = *reinterpret_cast<const f32x4*>(src);
+            if (p.gnA) {
+                v = v * gA + gB;
+                if (p.gn_silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                }
+            }
         }
         return v;
     };
@@ -201,6 +224,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     };
 
     // ---- prologue: chunk 0 halo, first B fragments
+    load_gn(0, gA, gB);
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_item(k, 0));
 #pragma unroll
@@ -210,6 +234,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
         const bool halo_next = (ch + 1) < nchunks;
+        load_gn(ch + 1, gA, gB);                 // every halo fetch of this iteration is for chunk ch + 1
         if constexpr (TAPS == 9) {
             // A and B fragments are fetched one k-step ahead into the other half of a ping-pong register pair
             // (4 k-steps per tap = even, so the roles are compile-time constants and no copies are needed).
@@ -467,12 +492,31 @@ __global__ void __launch_bounds__(512, 2)
     const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
 
     auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
+    // fused GroupNorm: this thread always loads the same 4 channels of a chunk, so one coefficient pair per chunk
+    const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
+    auto load_gn = [&](int ch, f32x4& cA, f32x4& cB) {
+        cA = f32x4{1.f, 1.f, 1.f, 1.f};
+        cB = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = ch * ROWF + (hslot << 2);
+        if (p.gnA && c < Ctot) {
+            cA = *reinterpret_cast<const f32x4*>(p.gnA + (size_t)gimg * p.ld_gn + c);
+            cB = *reinterpret_cast<const f32x4*>(p.gnB + (size_t)gimg * p.ld_gn + c);
+        }
+    };
+    f32x4 gA, gB;            // coefficients of the chunk whose halo is being fetched
     auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int c = ch * ROWF + (hslot << 2);
         if (g >= 0 && c < Ctot) {
             const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
             v = *reinterpret_cast<const f32x4*>(src);
+            if (p.gnA) {
+                v = v * gA + gB;
+                if (p.gn_silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                }
+            }
         }
         return v;
     };
@@ -548,6 +592,7 @@ __global__ void __launch_bounds__(512, 2)
         }
     };
 
+    load_gn(0, gA, gB);
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
     load_b(bfr[0], 0, 0);
@@ -557,6 +602,7 @@ __global__ void __launch_bounds__(512, 2)
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
         const bool halo_next = (ch + 1) < nchunks;
+        load_gn(ch + 1, gA, gB);                 // every halo fetch of this iteration is for chunk ch + 1
         int nvalid = (p.NC32 - ch * NSUB) * 4;          // k-steps of this chunk that hold real channels
         if (nvalid > NSTEP) nvalid = NSTEP;
         f32x4 phb[3];
@@ -867,7 +913,8 @@ extern "C" int nd_repack_conv_weight(const float* w, float* w_out, int N, int C,
 extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                             const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                             const float* residual, int ldr, float* out, int ldo,
-                            int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream) {
+                            int NI, int H, int W, int N, int ksize, int flags, int variant,
+                            const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     const char* fn = "nd_conv_nhwc";
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
@@ -913,6 +960,18 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
+    a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
+    if (gnA) {
+        // one image per block, so that a thread's coefficient pair is fixed per chunk
+        ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1 && (ld_gn & 3) == 0 && aligned16(gnA) && aligned16(gnB), fn,
+                   "fused GroupNorm: bad coefficient arrays");
+        if (flat) {
+            ND_REQUIRE(((long)H * W) % V.bm() == 0, fn, "fused GroupNorm (1x1): H*W must be a multiple of the pixel tile");
+            a.gn_hw = H * W;
+        } else {
+            ND_REQUIRE(best_tp.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
+        }
+    }
     const int grid = a.mt * a.nt;
     const size_t lds = lds_bytes(taps, best_tp.hp);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -985,7 +1044,8 @@ extern "C" int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out,
 extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                                         const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                                         const float* residual, int ldr, float* out, int ldo,
-                                        int NI, int H, int W, int N, int flags, int variant, nd_stream_t stream) {
+                                        int NI, int H, int W, int N, int flags, int variant,
+                                        const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     const char* fn = "nd_conv3x3_winograd_nhwc";
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -1036,6 +1096,12 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.mt = best.tiles_x * best.tiles_y * best.groups;
     a.nt = (N + WN * 32 - 1) / (WN * 32);
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
+    a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
+    if (gnA) {
+        ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1 && (ld_gn & 3) == 0 && aligned16(gnA) && aligned16(gnB), fn,
+                   "fused GroupNorm: bad coefficient arrays");
+        ND_REQUIRE(best.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
+    }
     const int grid = a.mt * a.nt;
     size_t lds = (size_t)2 * best.hp * 128 * nsub;
     if (lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats

@@ -178,6 +178,31 @@ __global__ void __launch_bounds__(GN_NT)
     }
 }
 
+// coefficients of the fused form: y = x * A[img][c] + B[img][c]  (consumed by the conv loaders)
+__global__ void gn_coeffs_kernel(const double* stats, const float* gamma, const float* beta, const float* scale,
+                                 const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef, int C, int HW,
+                                 int G, float eps) {
+    const int img = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int cpg = C / G;
+    const int g = c / cpg;
+    const double inv_n = 1.0 / ((double)cpg * (double)HW);
+    const double mean = stats[((size_t)img * G + g) * 2 + 0] * inv_n;
+    double var = stats[((size_t)img * G + g) * 2 + 1] * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    double a = rstd * (double)gamma[c];
+    double b = (double)beta[c] - mean * a;
+    if (scale) {
+        const double sc = 1.0 + (double)scale[(size_t)img * ld_ss + c];
+        a *= sc;
+        b = b * sc + (double)shift[(size_t)img * ld_ss + c];
+    }
+    coefA[(size_t)img * ld_coef + c] = (float)a;
+    coefB[(size_t)img * ld_coef + c] = (float)b;
+}
+
 static int check_src(const char* fn, const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1, int G) {
     ND_REQUIRE(x0 != nullptr && C0 > 0 && (C0 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && aligned16(x0), fn,
                "x0: channels/stride must be multiples of 4, pointer 16-byte aligned");
@@ -248,5 +273,17 @@ extern "C" int nd_groupnorm_apply_nhwc(const float* x0, int C0, int ldx0, const 
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
                            gamma, beta, scale, shift, ld_ss, out, ldo, H, W, G, eps, silu, ppb);
+    return check_launch(fn);
+}
+
+extern "C" int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
+                                   const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
+                                   int NI, int C, int HW, int G, float eps, nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_coeffs";
+    ND_REQUIRE(stats && gamma && beta && coefA && coefB && NI > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, fn,
+               "bad arguments");
+    ND_REQUIRE((scale == nullptr) == (shift == nullptr) && ld_coef >= C, fn, "scale/shift go together; ld_coef >= C");
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3((C + 127) / 128, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
+                       stats, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef, C, HW, G, eps);
     return check_launch(fn);
 }

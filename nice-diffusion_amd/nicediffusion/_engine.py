@@ -41,6 +41,25 @@ class Act:
         return self.t.data_ptr()
 
 
+class Normed:
+    """GroupNorm output that has not been materialised: the consumer conv applies ``x * A + B`` (+SiLU) while loading.
+    ``coefA``/``coefB`` are fp32 [NI][C] device buffers filled by nd_groupnorm_coeffs."""
+    __slots__ = ('src', 'src2', 'coefA', 'coefB', 'C', 'silu', 'norm', 'scale_ptr', 'shift_ptr', 'ld_ss', 'slot')
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _fuse_gn_mode():
+    """0: never fold GroupNorm into the consumer conv; 1 (default): fold the affine-only norms (attention); 2: also fold
+    norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
+    (~8x for 384 channels on the Winograd tiles), which costs 20-25 % of the conv and far exceeds the 3.4 ms of the
+    separate HBM-bound apply pass, so SiLU norms keep their own kernel."""
+    import os
+    return int(os.environ.get('ND_FUSE_GN', '1'))
+
+
 class _Pool:
     """Plan-time buffer reuse: launches are stream-ordered, so a buffer can be handed out again as soon as the plan
     has emitted its last reader."""
@@ -109,7 +128,7 @@ class UNetPlan:
         return Act(self.pool.take(NI * H * W * C), NI, H, W, C)
 
     def _release(self, act):
-        if act is not None and act.t is not None:
+        if isinstance(act, Act) and act.t is not None:
             self.pool.give(act.t)
 
     def _packed(self, weight, pad_c_to=None):
@@ -156,6 +175,22 @@ class UNetPlan:
         module's parameter (packed here); output spatial size is src's, doubled when CONV_IN_UP2X is set.  For 3x3
         convolutions on even sizes the Winograd F(2x2,3x3) kernel competes with the direct kernel's tile shapes and
         the fastest measured implementation is kept."""
+        gn = [None, None, 0]
+        tmp = None
+        if isinstance(src, Normed):
+            nm = src
+            up_ = 1 if (flags & _hip.CONV_IN_UP2X) else 0
+            hw = (nm.src.H << up_) * (nm.src.W << up_)
+            # the fused form needs one image per block: every tile shape is <= 256 pixels
+            mode = _fuse_gn_mode()
+            if (mode >= 2 or (mode == 1 and not nm.silu)) and hw >= 256 and hw % 256 == 0 and rowbias is None:
+                src, src2 = nm.src, nm.src2
+                gn = [nm.coefA.data_ptr(), nm.coefB.data_ptr(), nm.C]
+                if nm.silu:
+                    flags |= _hip.CONV_GN_SILU
+            else:
+                tmp = self._materialise(nm)
+                src, src2 = tmp, None
         up = 1 if (flags & _hip.CONV_IN_UP2X) else 0
         NI, H, W = src.NI, src.H << up, src.W << up
         if out is None:
@@ -165,28 +200,41 @@ class UNetPlan:
         tail = [bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
-        key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None)
-        kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags)
+        key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
+        kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags, gn)
         if kind == 'wino':
             wq = self._packed_wino(weight, pad_c_to)
             self.keep.append(wq)
             self.packed_floats += wq.numel()
-            self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var], label, flops=fl,
-                       variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+            self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var] + gn, label,
+                       flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         else:
             wp = self._packed(weight, pad_c_to)
-            self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var], label, flops=fl,
+            self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var] + gn, label, flops=fl,
                        variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
+        if tmp is not None:
+            self._release(tmp)
         return out
 
-    def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags):
+    def _materialise(self, nm):
+        """Fallback for consumers that cannot fuse the GroupNorm affine: write the normalised tensor."""
+        s2 = (None, 0, 0) if nm.src2 is None else (nm.src2.ptr, nm.src2.C, nm.src2.ld)
+        out = self._new(nm.src.NI, nm.src.H, nm.src.W, nm.C)
+        args = [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', nm.slot),
+                nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr,
+                nm.ld_ss, out.ptr, out.ld, nm.src.NI, nm.src.H, nm.src.W, GN_GROUPS, GN_EPS,
+                _hip.GN_SILU if nm.silu else 0]
+        self._emit(self.lib.nd_groupnorm_apply_nhwc, args, 'gn.apply')
+        return out
+
+    def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
         """(kind, variant) for one conv launch.  Measured on the device: 3 timed launches per candidate -- every direct
         tile shape that fits and, for 3x3 on even sizes, the Winograd variants -- best kept and cached per shape.
         ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
         import os
-        NI, H, W, C, N, ksize, _, has_rb, _ = key
+        NI, H, W, C, N, ksize, _, has_rb, _, _ = key
         heur = ('direct', self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0))
         if not _autotune_enabled() or flops < 2e8:
             return heur
@@ -211,13 +259,13 @@ class UNetPlan:
         self.keep.pop()                               # tuning copy; the chosen kind is packed again by the caller
         self.packed_floats -= wp.numel()
         for v in range(self.lib.nd_conv_num_variants()):
-            ms = time_it(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v])
+            ms = time_it(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v] + gn)
             if ms is not None and (best_ms is None or ms < best_ms):
                 best, best_ms = ('direct', v), ms
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
             for v in range(self.lib.nd_conv_winograd_num_variants()):
-                ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v])
+                ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
             del wq
@@ -229,29 +277,40 @@ class UNetPlan:
         assert K % 4 == 0
         args = [src_ptr, K, K, None, 0, 0, self._packed(weight).data_ptr(),
                 None if bias is None else bias.detach().data_ptr(),
-                None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1]
+                None, 0, None, 0, out_ptr, N, 1, 1, M, N, 1, flags, -1, None, None, 0]
         var = self.lib.nd_conv_select_variant(1, 1, M, N, 1, flags, 0)
         self._emit(self.lib.nd_conv_nhwc, args, label, flops=2 * M * N * K, variant=('direct', var), ksize=1)
         self.flops += 2 * M * N * K
 
-    def groupnorm(self, src, norm, out=None, src2=None, scale_ptr=None, shift_ptr=None, ld_ss=0, silu=True,
-                  pool=False, label='gn'):
+    def groupnorm(self, src, norm, src2=None, scale_ptr=None, shift_ptr=None, ld_ss=0, silu=True, pool=False,
+                  label='gn'):
+        """GroupNorm(32) of src (concatenated with src2).  Emits the statistics pass and the coefficient kernel and
+        returns a ``Normed`` (applied by the consuming conv's loader); with ``pool`` the activated tensor is average
+        pooled, which needs the explicit apply kernel, and an Act is returned."""
         slot = self._gn_slots
         self._gn_slots += 1
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
-        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-        if out is None:
-            out = self._new(NI, Ho, Wo, C)
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
         stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS]
         self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
-        flags = (_hip.GN_SILU if silu else 0) | (_hip.GN_POOL2 if pool else 0)
-        apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot),
-                      norm.weight.detach().data_ptr(), norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
-                      out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags]
-        self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
-        return out
+        if pool:
+            out = self._new(NI, H // 2, W // 2, C)
+            flags = (_hip.GN_SILU if silu else 0) | _hip.GN_POOL2
+            apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot),
+                          norm.weight.detach().data_ptr(), norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
+                          out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags]
+            self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
+            return out
+        coefA = torch.empty(NI * C, dtype=torch.float32, device=self.device)
+        coefB = torch.empty(NI * C, dtype=torch.float32, device=self.device)
+        self.keep += [coefA, coefB]
+        self._emit(self.lib.nd_groupnorm_coeffs, [('gnstats', slot), norm.weight.detach().data_ptr(),
+                                                  norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
+                                                  coefA.data_ptr(), coefB.data_ptr(), C, NI, C, H * W, GN_GROUPS, GN_EPS],
+                   label + '.coeffs')
+        return Normed(src=src, src2=src2, coefA=coefA, coefB=coefB, C=C, silu=silu, norm=norm, scale_ptr=scale_ptr,
+                      shift_ptr=shift_ptr, ld_ss=ld_ss, slot=slot)
 
     # ------------------------------------------------------------------------------------------------ build
     def _build(self):
@@ -297,7 +356,7 @@ class UNetPlan:
             self.e_b = torch.cat([rb.step_embedding.bias.detach() for rb in res_blocks], 0).contiguous()
             self.e_all = torch.empty(NI * self.e_ld, **f32)
             args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self._packed(self.e_w).data_ptr(), self.e_b.data_ptr(),
-                    None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1]
+                    None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1, None, None, 0]
             var = lib.nd_conv_select_variant(1, 1, NI, self.e_ld, 1, 0, 0)
             self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=('direct', var), ksize=1)
             self.flops += 2 * NI * self.e_ld * ed
@@ -315,11 +374,10 @@ class UNetPlan:
             x_cur = self._run_block(block, x_cur, skips.pop(), owned=True, skip_owned=True)
         # output head: GN -> SiLU -> conv3x3 (model.py:446-449)
         h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
-        self._release(x_cur)
         out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
         self.conv(h, m.out[2].weight, m.out[2].bias.detach().data_ptr(), self.Cout, 3,
                   out=out_act, label='conv3x3')
-        self._release(h)
+        self._release(x_cur)
 
         # ---- GroupNorm statistics arena (float64 [slots][NI][32][2]); zeroed at the start of every run
         self.gn_stats = torch.zeros(max(1, self._gn_slots) * NI * GN_GROUPS * 2, dtype=torch.float64, device=dev)
@@ -386,7 +444,7 @@ class UNetPlan:
                                 silu=True, label='res.out_norm')
         else:
             h2 = self.groupnorm(h1, rb.out_norm, silu=True, label='res.out_norm')
-        self._release(h1)
+        # h1 stays alive until out_conv has been emitted: h2 is applied by that conv's loader
         # skip path
         flags = 0
         res = None
@@ -414,6 +472,7 @@ class UNetPlan:
         out = self.conv(h2, rb.out_conv.weight, rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
                         flags=flags, label='conv3x3')
         self._release(h2)
+        self._release(h1)
         if tmp is not None:
             self._release(tmp)
         return out

@@ -13,6 +13,7 @@ _LIB_PATH = os.environ.get('ND_HIP_LIB') or os.path.join(os.path.dirname(os.path
 CONV_IN_UP2X = 1
 CONV_RES_UP2X = 2
 CONV_SILU_OUT = 4
+CONV_GN_SILU = 8
 GN_SILU = 1
 GN_POOL2 = 2
 VAR_FIXED = 0
@@ -31,9 +32,10 @@ SIGNATURES = {
     'nd_timestep_embed': [_vp, _vp, _i, _i, _vp, _i, _vp],
     'nd_embedding_add_silu': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'nd_conv_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
-                     _i, _i, _i, _i, _i, _i, _i, _vp],
+                     _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_conv3x3_winograd_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
-                                 _i, _i, _i, _i, _i, _i, _vp],
+                                 _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    'nd_groupnorm_coeffs': [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _vp],

@@ -81,7 +81,7 @@ def test_conv3x3_all_variants(B, Cin, Cout, H, W):
     for v in [-1] + list(range(lib().nd_conv_num_variants())):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
         rc = lib().nd_conv_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
-                                out.data_ptr(), Cout, B, H, W, Cout, 3, 0, v, st())
+                                out.data_ptr(), Cout, B, H, W, Cout, 3, 0, v, None, None, 0, st())
         if rc != 0 and v >= 0:
             continue        # this tile shape does not fit this problem
         assert rc == 0, _hip.last_error()
@@ -113,13 +113,13 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
     for v in range(lib().nd_conv_winograd_num_variants()):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
-                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, st()))
+                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st()))
         got = from_nhwc(out, B, H, W, Cout)
         assert torch.isfinite(got).all(), v
         assert (got - ref).abs().max().item() < 2e-4, (v, (got - ref).abs().max().item())
     # odd sizes are refused (callers use the direct form)
     rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
-                                        out.data_ptr(), Cout, B, H - 1, W, Cout, 0, 0, st())
+                                        out.data_ptr(), Cout, B, H - 1, W, Cout, 0, 0, None, None, 0, st())
     assert rc == -1 and 'even' in _hip.last_error()
 
 
@@ -141,16 +141,16 @@ def test_conv3x3_winograd_fused_options():
         out = torch.empty(B * H * W * Cout, device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
                                                   rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
-                                                  Cout, 0, v, st()))
+                                                  Cout, 0, v, None, None, 0, st()))
         assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
         out = torch.empty(B * 4 * H * W * Cout, device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
                                                   rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout,
-                                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, v, st()))
+                                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, v, None, None, 0, st()))
         assert (from_nhwc(out, B, 2 * H, 2 * W, Cout) - ref2).abs().max().item() < 2e-4
         out = torch.empty(B * H * W * Cout, device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
-                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, _hip.CONV_SILU_OUT, v, st()))
+                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, _hip.CONV_SILU_OUT, v, None, None, 0, st()))
         assert (from_nhwc(out, B, H, W, Cout) - ref3).abs().max().item() < 2e-4
 
 
@@ -166,7 +166,7 @@ def test_conv3x3_fused_options():
     xad, xbd, bd, rbd, resd = nhwc(xa), nhwc(xb), b.to(DEV), rb.to(DEV), nhwc(res)
     _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
                                   rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W, Cout, 3, 0,
-                                  -1, st()))
+                                  -1, None, None, 0, st()))
     assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
     # upsampled input + upsampled residual: conv(interp(x)) + interp(r)
     x, r = rnd(B, C0, H, W, seed=7), rnd(B, Cout, H, W, seed=8)
@@ -178,7 +178,7 @@ def test_conv3x3_fused_options():
     xd, rd = nhwc(x), nhwc(r)
     _hip.check(lib().nd_conv_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
                                   rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout, 3,
-                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, -1, st()))
+                                  _hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X, -1, None, None, 0, st()))
     assert (from_nhwc(out, B, 2 * H, 2 * W, Cout) - ref).abs().max().item() < 2e-4
 
 
@@ -191,7 +191,7 @@ def test_gemm_1x1_and_silu(M, K, N):
     for v in [-1] + list(range(lib().nd_conv_num_variants())):
         out = torch.full((M * N,), float('nan'), device=DEV)
         rc = lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
-                                resd.data_ptr(), N, out.data_ptr(), N, 1, 1, M, N, 1, 0, v, st())
+                                resd.data_ptr(), N, out.data_ptr(), N, 1, 1, M, N, 1, 0, v, None, None, 0, st())
         if rc != 0 and v >= 0:
             continue
         assert rc == 0, _hip.last_error()
@@ -199,8 +199,62 @@ def test_gemm_1x1_and_silu(M, K, N):
         assert (out.cpu().view(M, N) - ref).abs().max().item() < 2e-4, v
     out = torch.empty(M * N, device=DEV)
     _hip.check(lib().nd_conv_nhwc(ad.data_ptr(), K, K, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
-                                  out.data_ptr(), N, 1, 1, M, N, 1, _hip.CONV_SILU_OUT, -1, st()))
+                                  out.data_ptr(), N, 1, 1, M, N, 1, _hip.CONV_SILU_OUT, -1, None, None, 0, st()))
     assert (out.cpu().view(M, N) - F.silu(F.linear(a, w, b))).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize('silu', [True, False])
+def test_conv_with_fused_groupnorm(silu):
+    """GroupNorm(+AdaGN)(+SiLU) of the conv INPUT folded into the loader (two-source concat input included):
+    direct 3x3 (every tile shape), Winograd, and 1x1, vs GN -> act -> conv on the CPU."""
+    B, C0, C1, Cout, H, W = 2, 64, 32, 64, 16, 16
+    C = C0 + C1
+    xa, xb = rnd(B, C0, H, W, seed=1) * 2 + 0.3, rnd(B, C1, H, W, seed=2)
+    x = torch.cat([xa, xb], 1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    scale, shift = 0.3 * rnd(B, C, seed=5), 0.3 * rnd(B, C, seed=6)
+    h = F.group_norm(x, 32, gamma, beta, 1e-5) * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    if silu:
+        h = F.silu(h)
+    w3, w1, b = rnd(Cout, C, 3, 3, seed=7, scale=0.05), rnd(Cout, C, seed=8, scale=0.05), rnd(Cout, seed=9)
+    ref3, ref1 = F.conv2d(h, w3, b, padding=1), F.conv2d(h, w1[:, :, None, None], b)
+    xad, xbd, bd = nhwc(xa), nhwc(xb), b.to(DEV)
+    stats = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, None, 0, stats.data_ptr(), B,
+                                             H * W, 32, st()))
+    gd, btd, scd, shd = gamma.to(DEV), beta.to(DEV), scale.to(DEV), shift.to(DEV)
+    cA, cB = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
+    _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), gd.data_ptr(), btd.data_ptr(), scd.data_ptr(), shd.data_ptr(), C,
+                                         cA.data_ptr(), cB.data_ptr(), C, B, C, H * W, 32, 1e-5, st()))
+    flags = _hip.CONV_GN_SILU if silu else 0
+    wd3, wd1, wq = pack_w(w3), pack_w(w1), pack_wino(w3)
+    ran = 0
+    for v in range(lib().nd_conv_num_variants()):
+        for (wd, ks, ref) in ((wd3, 3, ref3), (wd1, 1, ref1)):
+            out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+            rc = lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                    None, 0, out.data_ptr(), Cout, B, H, W, Cout, ks, flags, v, cA.data_ptr(), cB.data_ptr(), C,
+                                    st())
+            if rc != 0:
+                continue
+            err = (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item()
+            assert err < 3e-4, (v, ks, err)
+            ran += 1
+    assert ran >= 8
+    for v in range(lib().nd_conv_winograd_num_variants()):
+        out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+        rc = lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wq.data_ptr(), bd.data_ptr(), None,
+                                            0, None, 0, out.data_ptr(), Cout, B, H, W, Cout, flags, v, cA.data_ptr(),
+                                            cB.data_ptr(), C, st())
+        if rc != 0:
+            assert 'one image per block' in _hip.last_error()
+            continue
+        err = (from_nhwc(out, B, H, W, Cout) - ref3).abs().max().item()
+        assert err < 3e-4, (v, err)
+    # small images (several per block) are refused: callers materialise the normalised tensor instead
+    rc = lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd3.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                            out.data_ptr(), Cout, B * 4, 8, 8, Cout, 3, flags, 0, cA.data_ptr(), cB.data_ptr(), C, st())
+    assert rc == -1
 
 
 def test_conv_direct_stride2():

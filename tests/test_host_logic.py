@@ -223,7 +223,7 @@ def test_library_exports_every_header_symbol():
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected on the host before any launch."""
     lib = _hip.load()
-    rc = lib.nd_conv_nhwc(None, 32, 32, None, 0, 0, None, None, None, 0, None, 0, None, 32, 1, 8, 8, 32, 3, 0, -1,
+    rc = lib.nd_conv_nhwc(None, 32, 32, None, 0, 0, None, None, None, 0, None, 0, None, 32, 1, 8, 8, 32, 3, 0, -1, None, None, 0,
                           None)
     assert rc == -1 and 'null' in _hip.last_error()
     rc = lib.nd_attention_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)

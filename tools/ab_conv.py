@@ -32,7 +32,7 @@ for (NI, H, W, C, N, ks, var) in shapes:
     res = [[] for _ in L]
     def run(i, n):
         for _ in range(n):
-            rc = L[i].nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, ws[i].data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, ks, 0, var, st)
+            rc = L[i].nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, ws[i].data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, ks, 0, var, None, None, 0, st)
             assert rc == 0
     for i in range(len(L)):
         run(i, 3)

@@ -29,7 +29,7 @@ for (NI, H, W, C, N, var) in shapes:
     res = [[] for _ in L]
     def run(i, n):
         for _ in range(n):
-            assert L[i].nd_conv3x3_winograd_nhwc(x.data_ptr(), C, C, None, 0, 0, ws[i].data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, 0, var, st) == 0
+            assert L[i].nd_conv3x3_winograd_nhwc(x.data_ptr(), C, C, None, 0, 0, ws[i].data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, 0, var, None, None, 0, st) == 0
     for i in range(len(L)): run(i, 2)
     torch.cuda.synchronize()
     for r in range(rounds):

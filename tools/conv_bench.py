@@ -28,15 +28,15 @@ if wino:
     ref_out = torch.empty_like(out)
     wd = torch.empty(lib.nd_conv_weight_floats(N, C, 3), device=dev)
     assert lib.nd_repack_conv_weight(w0.data_ptr(), wd.data_ptr(), N, C, 3, st) == 0
-    assert lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), b.data_ptr(), None, 0, None, 0, ref_out.data_ptr(), N, NI, H, W, N, 3, 0, -1, st) == 0
+    assert lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), b.data_ptr(), None, 0, None, 0, ref_out.data_ptr(), N, NI, H, W, N, 3, 0, -1, None, None, 0, st) == 0
 for v in variants:
     def run():
         if wino:
-            rc = lib.nd_conv3x3_winograd_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, 0, v, st)
+            rc = lib.nd_conv3x3_winograd_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N, NI, H, W, N, 0, v, None, None, 0, st)
             assert rc == 0, _hip.last_error()
             return
         rc = lib.nd_conv_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
-                              NI, H, W, N, ks, 0, v, st)
+                              NI, H, W, N, ks, 0, v, None, None, 0, st)
         assert rc == 0, _hip.last_error()
     try:
         run()
