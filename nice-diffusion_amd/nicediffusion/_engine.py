@@ -24,6 +24,32 @@ def _autotune_enabled():
     return os.environ.get('ND_AUTOTUNE', '1') != '0'
 
 
+def _tune_cache_path():
+    import os
+    return os.environ.get('ND_TUNE_CACHE')
+
+
+def _load_tune_cache():
+    """Optional on-disk cache of the measured choices (ND_TUNE_CACHE=file.json): lets a second process (e.g. a run under
+    rocprofv3) start without the tuning launches."""
+    import json
+    import os
+    path = _tune_cache_path()
+    if path and os.path.exists(path) and not _TUNED:
+        try:
+            for k, v in json.load(open(path)).items():
+                _TUNED[tuple(json.loads(k))] = tuple(v)
+        except (ValueError, OSError):
+            pass
+
+
+def _save_tune_cache():
+    import json
+    path = _tune_cache_path()
+    if path:
+        json.dump({json.dumps(list(k)): list(v) for k, v in _TUNED.items()}, open(path, 'w'))
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -116,7 +142,11 @@ class UNetPlan:
         self.out = torch.empty(NI * R * R * self.Cout_p, **f32)
         self._gn_slots = 0
         self._gn_users = []     # ops needing the stats base pointer patched in
+        _load_tune_cache()
+        n_tuned = len(_TUNED)
         self._build()
+        if len(_TUNED) != n_tuned:
+            _save_tune_cache()
         self.weight_signature = model._weight_signature()
 
     # ------------------------------------------------------------------------------------------------ emit helpers
