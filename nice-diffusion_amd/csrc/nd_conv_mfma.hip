@@ -497,13 +497,23 @@ __global__ void __launch_bounds__(512, 2)
     const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
     const int n0 = nblk * BN;
 
+    // LDS image of the halo: pixel hp (= image-local row Y, column X of the (TH+2) x (TW+2) halo) owns ROWF floats.
+    // Lanes of one ds_read_b128 group are a 4 x 4 block of Winograd tiles, i.e. pixels 2 apart in X and Y with the
+    // same parity, so the 16-byte slot is XOR-swizzled with a key built from the TILE coordinates
+    // key = ((Y>>1)&3)<<2 | ((X>>1)&3): 16 distinct keys per group -> conflict-free.  For 128-byte pixel rows the
+    // pixel parity is the 4th slot bit (two pixels share a 256-byte bank row; both have the same key).
+    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {
+        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
+        if (SPR == 8) return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
+        return hp * ROWF + ((slot ^ key) << 2);
+    };
     const int hslot = tid % SPR;
     const int hrow0 = tid / SPR;
-    int gpix[MAXHI];
+    int gpix[MAXHI], hoff[MAXHI];
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) {
         const int hp = hrow0 + k * (NT / SPR);
-        int g = -1;
+        int g = -1, ho = -1;
         if (hp < HP) {
             const int li = hp / HPI;
             const int rem = hp - li * HPI;
@@ -513,13 +523,14 @@ __global__ void __launch_bounds__(512, 2)
             const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
             if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
                 g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+            ho = lds_off(hp, hy, hx, hslot);
         }
         gpix[k] = g;
+        hoff[k] = ho;
     }
     const int Ctot = p.C0 + p.C1;
     const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
 
-    auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
     // fused GroupNorm: this thread always loads the same 4 channels of a chunk, so one coefficient pair per chunk
     const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
     auto load_gn = [&](int ch, f32x4& cA, f32x4& cB) {
@@ -549,11 +560,7 @@ __global__ void __launch_bounds__(512, 2)
         return v;
     };
     auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        const int hp = hrow0 + k * (NT / SPR);
-        if (hp < HP) {
-            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
-            *reinterpret_cast<f32x4*>(dst) = v;
-        }
+        if (hoff[k] >= 0) *reinterpret_cast<f32x4*>(smem + buf * (HP * ROWF) + hoff[k]) = v;
     };
 
     // (B^T d)[xi][j] = d[ra][j] + sgn * d[rb][j]:  xi=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
@@ -574,9 +581,8 @@ __global__ void __launch_bounds__(512, 2)
         const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ha = base + ra * HW + j, hb = base + rb * HW + j;
-            off_a[mt][j] = ha * ROWF + ((lh ^ swz(ha)) << 2);
-            off_b[mt][j] = hb * ROWF + ((lh ^ swz(hb)) << 2);
+            off_a[mt][j] = lds_off(base + ra * HW + j, 2 * t_y + ra, 2 * t_x + j, lh);
+            off_b[mt][j] = lds_off(base + rb * HW + j, 2 * t_y + rb, 2 * t_x + j, lh);
         }
     }
 
