@@ -106,13 +106,22 @@ def roofline_from(rows, lib):
         lib.nd_conv_variant_info(var, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         kname = 'nd::conv_mfma_kernel<{}x{} tile, {} threads, {} taps>'.format(bm.value, bn.value, nt.value, ksize * ksize)
         executed = 1.0
+    traffic = None
+    try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+        for name, rec in pmc.items():
+            if isinstance(rec, dict) and kname.startswith(name) and 'hbm_bytes' in rec:
+                traffic = {'hbm_bytes_per_launch': rec['hbm_bytes'], 'algorithmic_bytes': rec['algorithmic_bytes'],
+                           'shape': rec['shape'], 'source': 'profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)'}
+    except (OSError, ValueError):
+        pass
     achieved = g['flops'] / (g['ms'] * 1e-3) / 1e12
     total_ms = sum(r['ms'] for r in rows)
     conv_ms = sum(v['ms'] for v in groups.values())
     conv_fl = sum(v['flops'] for v in groups.values())
     return {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_F32_TFLOPS, 4), 'traffic': traffic,
         'kernel': kname,
         'note': 'achieved = algorithmic (direct-convolution) flops / time; the Winograd kernel executes 4/9 of them '
                 'on the matrix pipe, so frac can exceed 1' if kind == 'wino' else 'achieved = algorithmic flops / time',
