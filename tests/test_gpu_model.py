@@ -83,6 +83,24 @@ def test_preset_64_forward_and_batch_consistency(golden_dir):
     assert np.abs(ob[5] - g['out'][0]).max() < 2e-4
 
 
+@pytest.mark.parametrize('preset', ['OPENAI_128_MODEL_ARGS', 'OPENAI_256_MODEL_ARGS'])
+def test_large_presets_forward_vs_oracle(preset):
+    """128x128 (4 heads: head dims 128/192/256) and 256x256 (6 levels) presets, B=1, against the CPU oracle run on this
+    box (the oracle is pinned to the reference on the smaller presets; these weights are too big to commit)."""
+    cfg = dict(getattr(DA, preset))
+    sd = UO.synth_state_dict(cfg, seed=4321)
+    m = DiffusionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).eval()
+    R = cfg['resolution']
+    torch.manual_seed(1)
+    x, t, y = torch.randn(1, 3, R, R), torch.tensor([321]), torch.tensor([7])
+    out = m(x.to(DEV), t.to(DEV), y.to(DEV)).cpu()
+    ref = UO.unet_forward(sd, cfg, x, t, y)
+    err = (out - ref).abs().max().item()
+    assert ref.abs().max().item() > 0.05 and err < 1e-3, (err, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('name', sorted(SAMPLER_CASES))
 def test_sampler_loops_vs_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, 'sampler_{}.npz'.format(name)))
