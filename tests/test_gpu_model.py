@@ -215,3 +215,38 @@ def test_full_size_properties_config2():
     a = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     b = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5
+
+
+def test_sample_cli_end_to_end(tmp_path, golden_dir):
+    """scripts/sample.py with --custom flags on a tiny checkpoint: images come out as JPGs named like the reference's
+    ({label}_sample{n}.jpg), --cpu is refused, and the uint8 conversion matches the oracle's loop output."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'nice-diffusion_amd', 'scripts'))
+    import sample
+    cfg = dict(TINY_CFGS['adagn_updown'])
+    sd = UO.synth_state_dict(cfg, seed=11)
+    ckpt = str(tmp_path / 'tiny_model.pt')
+    torch.save(sd, ckpt)
+    out_dir = str(tmp_path) + '/'
+    argv = ['--model_path', ckpt, '--custom', '--batch_size', '2', '--num_samples', '2', '--resolution', '16',
+            '--model_channels', '32', '--channel_mult', '1/2', '--num_res_blocks', '1', '--attention_resolutions', '8',
+            '--num_classes', '10', '--num_head_channels', '32', '--split_qkv_first', '--resblock_updown', '--use_adaptive_gn',
+            '--rescaled_num_steps', '5', '--beta_schedule', 'cosine', '--sampling_var_type', 'learned_interpolation',
+            '--use_ddim', '--ddim_eta', '0.0', '--seed', '0', '--labels', '3/4', '--save_path', out_dir]
+    sample.main(argv)
+    names = sorted(f for f in os.listdir(out_dir) if f.endswith('.jpg'))
+    assert names == ['3_sample0.jpg', '3_sample1.jpg', '4_sample0.jpg', '4_sample1.jpg']
+    # same seed -> same x_T as the script drew (torch.manual_seed(0); randn on the CPU generator)
+    torch.manual_seed(0)
+    xT = torch.randn(2, 3, 16, 16)
+    so = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(sd, cfg, a, b, c), DO.Schedule(1000, 5, 'cosine'),
+                          'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    ref = so.denoise(xT, torch.tensor([3, 3]))
+    ref_u8 = ((ref + 1) * 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    m = build(cfg, seed=11)
+    d = Diffusion(m, 1000, 5, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0, device=DEV)
+    got = sample.to_uint8_hwc(d.denoise(x=xT, kwargs={'y': torch.tensor([3, 3]).to(DEV)}, batch_size=2, progress=False))
+    assert np.abs(got.astype(int) - ref_u8.astype(int)).max() <= 1
+    with pytest.raises(_hip.NdHipError):
+        sample.main(argv + ['--cpu'])
