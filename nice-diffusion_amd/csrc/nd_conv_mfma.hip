@@ -459,11 +459,11 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 // r_xi[b] = sum_nu At[b][nu] M[xi][nu] computed in registers and exchanged once through LDS in the epilogue.
 // NSUB = 32-channel sub-chunks per LDS chunk (2 halves the barrier count; needs the smaller TMW = 1 halo);
 // APF = read the raw patch entries of the next k-step ahead of this step's MFMAs (TMW = 1 has the registers for it).
-template <int TMW, int NSUB, bool APF>
-__global__ void __launch_bounds__(512, 2)
+template <int TMW, int NSUB, bool APF, int WNT>
+__global__ void __launch_bounds__(256 * WNT, (WNT == 1) ? 3 : 2)
     conv_wino_kernel(const ConvArgs p) {
-    constexpr int NT = 512;
-    constexpr int BN = 64;
+    constexpr int NT = 256 * WNT;                   // 4 waves (one per transform row xi) per 32-channel n tile
+    constexpr int BN = 32 * WNT;
     constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
     constexpr int FRAGS = 64;
     constexpr int MAXHI = 6;                        // halo float4 items per thread per chunk (two batches of 3)
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(512, 2)
         }
     }
 
-    int ntile = nblk * 2 + wn;
+    int ntile = nblk * WNT + wn;
     if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
     // this wave's 4 fragments of k-step kc: positions 4*xi .. 4*xi+3 -> contiguous 4 KiB
     const float* bp = p.w + ((size_t)ntile * FRAGS + 4 * xi) * 256 + lane * 4;
@@ -1034,13 +1034,14 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
 
 // ---- Winograd F(2x2,3x3) entry points -------------------------------------------------------------------------
 namespace nd {
-// {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch}; BN = 64
-static const int kWinoCfg[][3] = {{2, 1, 0}, {1, 1, 0}, {1, 1, 1}, {1, 2, 1}, {1, 2, 0}};
-static constexpr int kNumWino = 5;
+// {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch,
+//  n tiles of 32 channels per block (4 waves each)}
+static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}};
+static constexpr int kNumWino = 6;
 
-template <int TMW, int NSUB, bool APF>
+template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino_kernel<TMW, NSUB, APF>;
+    auto kern = conv_wino_kernel<TMW, NSUB, APF, WNT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1051,7 +1052,7 @@ static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WNT), lds, s, a);
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
 
@@ -1092,9 +1093,9 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const int WM = kWinoCfg[variant][0], WN = 2;
+    const int WM = kWinoCfg[variant][0], WN = kWinoCfg[variant][3];
     const int nsub = kWinoCfg[variant][1];
-    const int nt = 512;
+    const int nt = 256 * WN;
     const int maxhi = 6;
     // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
     const int bm = WM * 128;
@@ -1138,14 +1139,15 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     }
     const int grid = a.mt * a.nt;
     size_t lds = (size_t)2 * best.hp * 128 * nsub;
-    if (lds < 64 * 1024) lds = 64 * 1024;       // epilogue exchange: 8 waves x 2 x 16 x 64 floats
+    if (lds < (size_t)WN * 32 * 1024) lds = (size_t)WN * 32 * 1024;     // epilogue exchange: 4*WN waves x 2 x 16 x 64 floats
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
-        case 0: return launch_wino<2, 1, false>(a, grid, lds, s);
-        case 1: return launch_wino<1, 1, false>(a, grid, lds, s);
-        case 2: return launch_wino<1, 1, true>(a, grid, lds, s);
-        case 3: return launch_wino<1, 2, true>(a, grid, lds, s);
-        case 4: return launch_wino<1, 2, false>(a, grid, lds, s);
+        case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
+        case 1: return launch_wino<1, 1, false, 2>(a, grid, lds, s);
+        case 2: return launch_wino<1, 1, true, 2>(a, grid, lds, s);
+        case 3: return launch_wino<1, 2, true, 2>(a, grid, lds, s);
+        case 4: return launch_wino<1, 2, false, 2>(a, grid, lds, s);
+        case 5: return launch_wino<1, 1, false, 1>(a, grid, lds, s);
     }
     return fail_arg(fn, "bad variant");
 }
