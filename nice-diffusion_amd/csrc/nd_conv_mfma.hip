@@ -423,6 +423,180 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 1x1 "stream" form (flat pixel list only): a 1x1 convolution is a plain GEMM, and with K = Cin of a few hundred a
+// block lives for ~12 chunks -- too short to amortise the LDS staging + barrier per chunk of the kernel above.  Here
+// BOTH operands go straight from global memory into MFMA fragments: lane (i = lane&31, h = lane>>5) loads the 16 bytes
+// k in {8s+4h..+3} of ITS pixel row (the fragment order the packed weights already use), so there is no LDS, no
+// barrier, and waves run fully decoupled with a 3-step-deep register ring hiding L2 latency.  The 4 k-steps of a
+// 32-channel chunk touch the same 128-byte line of a pixel row back to back (served by L1 after the first).
+template <int WM, int WN, int TM, int TN, int OCC, bool GN>
+__global__ void __launch_bounds__(WM* WN * 64, GN ? 2 : OCC)
+    gemm_stream_kernel(const ConvArgs p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int D = 3;                               // prefetch distance in k-steps (ring of 4)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nblk = idp / p.mt;
+    const int mblk = idp - nblk * p.mt;
+    const int M = p.W;                                  // flat pixel list
+    const int m0 = mblk * BM;
+    const int n0 = nblk * BN;
+    const int Ctot = p.C0 + p.C1;
+
+    // per-lane pixel rows (clamped: rows past M compute garbage that the epilogue drops)
+    const float* r0[TM];
+    const float* r1[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        int m = m0 + (wm * TM + mi) * 32 + l31;
+        m = m < M ? m : M - 1;
+        r0[mi] = p.x0 + (size_t)m * p.ldx0 + 4 * lh;
+        r1[mi] = p.x1 + (size_t)m * p.ldx1 + 4 * lh - p.C0;
+    }
+    const float* bp[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        int ntile = nblk * (BN / 32) + wn * TN + ni;
+        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
+        bp[ni] = p.w + (size_t)ntile * (4 * 256) + lane * 4;
+    }
+    const size_t c32_jump = (size_t)(p.NT32 - 1) * (4 * 256);
+    const float* ga = nullptr;
+    const float* gb = nullptr;
+    if constexpr (GN) {
+        const int gimg = m0 / p.gn_hw;
+        ga = p.gnA + (size_t)gimg * p.ld_gn + 4 * lh;
+        gb = p.gnB + (size_t)gimg * p.ld_gn + 4 * lh;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    f32x4 xa[4][TM], wb[4][TN], ca[4], cb[4];
+    int cnext = 0;          // first channel of the next k-step to fetch
+    int ld_in_c32 = 0;
+    auto fetch = [&](int slot) {
+        const int c = cnext + 4 * lh;
+        const bool ok = c < Ctot;          // also keeps the run-ahead past the last chunk inside the row
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const float* src = (c < p.C0) ? (r0[mi] + cnext) : (r1[mi] + cnext);
+            src = ok ? src : r0[mi];
+            xa[slot][mi] = *reinterpret_cast<const f32x4*>(src);
+        }
+        if constexpr (GN) {
+            const int cc = ok ? cnext : 0;
+            ca[slot] = *reinterpret_cast<const f32x4*>(ga + cc);
+            cb[slot] = *reinterpret_cast<const f32x4*>(gb + cc);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            wb[slot][ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+            bp[ni] += 256;
+        }
+        if (++ld_in_c32 == 4) {
+            ld_in_c32 = 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bp[ni] += c32_jump;
+        }
+        cnext += 8;
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d);
+    const bool ragged = (Ctot & 31) != 0;   // last chunk holds channels >= Ctot: the weights there are zero, but
+                                            // whatever was read in their place may be Inf / NaN
+    for (int c32 = 0; c32 < p.NC32; ++c32) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            fetch((kc + D) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GN) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    f32x4 v = xa[kc][mi] * ca[kc] + cb[kc];
+                    if (p.gn_silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                    }
+                    xa[kc][mi] = v;
+                }
+            }
+            if (ragged && c32 == p.NC32 - 1) {
+                const bool keep = (c32 * 32 + kc * 8 + 4 * lh) < Ctot;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xa[kc][mi][e] = keep ? xa[kc][mi][e] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kc][ni][j], xa[kc][mi][j], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (D^T layout, see conv_mfma_kernel): one pixel and 4 consecutive channels per register group
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + l31;
+        if (m < M) {
+            float* orow = p.out + (size_t)m * p.ldo;
+            const float* rr = p.res ? p.res + (size_t)m * p.ldr : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                    if (n + 3 < p.N && vec_ok) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rr) v += *reinterpret_cast<const f32x4*>(rr + n);
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(orow + n) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = acc[mi][ni][4 * g4 + e];
+                                if (p.bias) v += p.bias[n + e];
+                                if (rr) v += rr[n + e];
+                                if (p.silu_out) v = fast_silu(v);
+                                orow[n + e] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Weights [N][C][k][k] (OIHW; also Conv1d [N][C][1] and Linear [N][C]) -> fragment order
 //   out[((((c32*NT32 + ntile)*taps + tap)*4 + kc)*64 + lane)*4 + j] = w[n = ntile*32 + (lane&31)][c = c32*32 + kc*8 + (lane>>5)*4 + j][tap]
 // zero for n >= N, c >= C, and for the padding chunks (c32 in [ceil(C/32), nc32_padded(C)]).
@@ -800,8 +974,23 @@ static const Variant kVariants[] = {
     {2, 2, 2, 1, 2},   // 6: 128 x  64, 4 waves
     {2, 2, 1, 1, 4},   // 7:  64 x  64, 4 waves
     {2, 1, 1, 1, 4},   // 8:  64 x  32, 2 waves
+    // 1x1 stream form (gemm_stream_kernel; flat pixel lists only, never chosen by the cost model)
+    {2, 2, 2, 3, 2},   // 9:  128 x 192
+    {2, 2, 2, 2, 3},   // 10: 128 x 128
+    {2, 2, 1, 3, 3},   // 11:  64 x 192
+    {4, 1, 2, 3, 2},   // 12: 256 x  96
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+static constexpr int kFirstStream = 9;
+
+template <int WM, int WN, int TM, int TN, int OCC>
+static int launch_stream(const ConvArgs& a, int grid, hipStream_t s) {
+    if (a.gnA)
+        hipLaunchKernelGGL((gemm_stream_kernel<WM, WN, TM, TN, OCC, true>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_stream_kernel<WM, WN, TM, TN, OCC, false>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    return check_launch("nd_conv_nhwc");
+}
 
 template <int WM, int WN, int TM, int TN, int TAPS, int OCC>
 static int launch_variant(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -891,7 +1080,7 @@ static int select_variant(int variant, int taps, int pNI, int pH, int pW, int N,
     int best_v = -1;
     TilePlan best_tp{};
     double best_cost = 0;
-    for (int v = 0; v < kNumVariants; ++v) {
+    for (int v = 0; v < kFirstStream; ++v) {
         if (variant >= 0 && v != variant) continue;
         const Variant& V = kVariants[v];
         if (taps != 9 && V.bm() * 16 / V.nt() > 8) continue;      // 1x1: one halo item per k-step
@@ -975,9 +1164,19 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const bool flat = use_flat(taps, flags, rowbias);
     if (flat) { pNI = 1; pH = 1; pW = (int)M; }
 
+    ND_REQUIRE(variant < kNumVariants, fn, "bad variant");
+    const bool stream_form = variant >= kFirstStream;
+    if (stream_form) ND_REQUIRE(flat, fn, "stream variants take plain 1x1 convolutions (flat pixel list) only");
     TilePlan best_tp{};
-    const int best_v = select_variant(variant, taps, pNI, pH, pW, N, &best_tp);
-    if (best_v < 0) return fail_arg(fn, "no tile variant fits this shape");
+    int best_v = variant;
+    if (stream_form) {
+        const int bm = kVariants[variant].bm();
+        best_tp.thl = 0; best_tp.twl = ilog2(bm); best_tp.nibl = 0;
+        best_tp.tiles_x = (int)((M + bm - 1) / bm); best_tp.tiles_y = 1; best_tp.groups = 1; best_tp.hp = bm;
+    } else {
+        best_v = select_variant(variant, taps, pNI, pH, pW, N, &best_tp);
+        if (best_v < 0) return fail_arg(fn, "no tile variant fits this shape");
+    }
 
     const Variant& V = kVariants[best_v];
     ConvArgs a;
@@ -1009,6 +1208,12 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const int grid = a.mt * a.nt;
     const size_t lds = lds_bytes(taps, best_tp.hp);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (stream_form ? best_v : -1) {
+        case 9: return launch_stream<2, 2, 2, 3, 2>(a, grid, s);
+        case 10: return launch_stream<2, 2, 2, 2, 3>(a, grid, s);
+        case 11: return launch_stream<2, 2, 1, 3, 3>(a, grid, s);
+        case 12: return launch_stream<4, 1, 2, 3, 2>(a, grid, s);
+    }
     return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
 }
 

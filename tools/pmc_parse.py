@@ -1,6 +1,6 @@
 import csv, collections, glob, sys
 d=sys.argv[1]
-cc=glob.glob(d+'/*/*_counter_collection.csv')[0]
+cc=(glob.glob(d+'/*/*_counter_collection.csv')+glob.glob(d+'/*_counter_collection.csv'))[0]
 rows=list(csv.DictReader(open(cc)))
 acc=collections.defaultdict(lambda: collections.defaultdict(float))
 names={}
