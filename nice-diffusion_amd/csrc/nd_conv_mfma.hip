@@ -24,6 +24,7 @@
 //   grid        one block per (m tile, n tile), remapped so that each XCD gets a contiguous, n-major range of
 //               tiles (blocks resident on one XCD stream the same weight fragments through that XCD's L2).
 #include "nd_common.h"
+#include <stdlib.h>
 
 #ifndef ND_SETPRIO
 #define ND_SETPRIO 0
@@ -54,12 +55,46 @@ struct ConvArgs {
     int NC32;          // ceil(Cin / 32)
     int thl, twl, nibl;   // log2 of tile height / width / images per block
     int tiles_x, tiles_y, mt, nt;
+    int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
     int silu_out;
     // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
     const float* gnA;
     const float* gnB;
     int ld_gn, gn_silu, gn_hw;    // gn_hw > 0: flat pixel list, image = pixel / gn_hw
 };
+
+// Block -> tile order.  The n tiles are taken in groups of `ngroup`; inside a group the walk is m-major with n fastest,
+// so the blocks resident at one time on an XCD (consecutive ids) cover a few m tiles x ngroup n tiles: each input tile is
+// pulled from HBM once per GROUP and shared through L2 by the ngroup blocks that use it, each weight slab once per m
+// row.  ngroup = 1 is the n-major order (weights stay put, inputs re-read nt times), ngroup = nt the m-major one.
+__device__ inline void tile_of(int idp, int mt, int nt, int ngroup, int& mblk, int& nblk) {
+    const int per_group = ngroup * mt;
+    const int g = idp / per_group;
+    const int rem = idp - g * per_group;
+    const int left = nt - g * ngroup;
+    const int gn = left < ngroup ? left : ngroup;
+    mblk = rem / gn;
+    nblk = g * ngroup + (rem - mblk * gn);
+}
+
+static int env_ngroup() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("ND_NGROUP");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
+// n tiles per group.  Measured with FETCH_SIZE on B=64 layers (tools/ngroup_fetch.sh): all n tiles when the whole
+// weight tensor sits comfortably in an XCD's 4 MiB L2 (input then crosses HBM once: 333 MB instead of 1245 MB per
+// launch for 64x64x192->192), otherwise 4 (786 vs 1327 MB for 32x32x384->384; m-major thrashes the weights: 1883 MB).
+// Run time is within 1 % across orders -- the point is not to burn HBM bandwidth and power on re-reads.
+static int pick_ngroup(int nt, size_t bytes_per_ntile) {
+    int g = env_ngroup();
+    if (g <= 0) g = ((size_t)nt * bytes_per_ntile <= ((size_t)3 << 20)) ? nt : 4;
+    return g > nt ? nt : g;
+}
 
 __host__ __device__ inline int nc32_padded(int C) {
     const int c = (C + 31) / 32;
@@ -95,8 +130,8 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     const int total = gridDim.x;
     const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
     const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int nblk = idp / p.mt;
-    const int mblk = idp - nblk * p.mt;
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
     const int tx = mblk % p.tiles_x;
     const int tmp = mblk / p.tiles_x;
     const int ty = tmp % p.tiles_y;
@@ -448,8 +483,8 @@ __global__ void __launch_bounds__(WM* WN * 64, GN ? 2 : OCC)
     const int total = gridDim.x;
     const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
     const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int nblk = idp / p.mt;
-    const int mblk = idp - nblk * p.mt;
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
     const int M = p.W;                                  // flat pixel list
     const int m0 = mblk * BM;
     const int n0 = nblk * BN;
@@ -657,8 +692,8 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 1) ? 3 : 2)
     const int total = gridDim.x;
     const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
     const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int nblk = idp / p.mt;
-    const int mblk = idp - nblk * p.mt;
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
     const int tx = mblk % p.tiles_x;
     const int tmp = mblk / p.tiles_x;
     const int ty = tmp % p.tiles_y;
@@ -1192,6 +1227,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.tiles_x = best_tp.tiles_x; a.tiles_y = best_tp.tiles_y;
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
+    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -1335,6 +1371,7 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.tiles_x = best.tiles_x; a.tiles_y = best.tiles_y;
     a.mt = best.tiles_x * best.tiles_y * best.groups;
     a.nt = (N + WN * 32 - 1) / (WN * 32);
+    a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float));
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
