@@ -97,10 +97,11 @@ def roofline_from(rows, lib):
     key, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
     (kind, var), ksize = key
     if kind == 'wino':
-        cfg = ((2, 1, 'false', 2), (1, 1, 'false', 2), (1, 1, 'true', 2), (1, 2, 'true', 2), (1, 2, 'false', 2),
-               (1, 1, 'false', 1))[var]
+        bm, bn, nt, nsub, apf = (ctypes.c_int() for _ in range(5))
+        lib.nd_conv_winograd_variant_info(var, *(ctypes.byref(v) for v in (bm, bn, nt, nsub, apf)))
         kname = ('nd::conv_wino_kernel<{}, {}, {}, {}> (Winograd F(2x2,3x3) on fp32 MFMA; {} px x {} ch per block, '
-                 '{} threads)').format(cfg[0], cfg[1], cfg[2], cfg[3], cfg[0] * 128, cfg[3] * 32, cfg[3] * 256)
+                 '{} threads)').format(bm.value // 128, nsub.value, 'true' if apf.value else 'false', bn.value // 32,
+                                       bm.value, bn.value, nt.value)
         executed = 4.0 / 9.0
     else:
         bm, bn, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

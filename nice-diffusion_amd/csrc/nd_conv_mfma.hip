@@ -669,7 +669,7 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 // NSUB = 32-channel sub-chunks per LDS chunk (2 halves the barrier count; needs the smaller TMW = 1 halo);
 // APF = read the raw patch entries of the next k-step ahead of this step's MFMAs (TMW = 1 has the registers for it).
 template <int TMW, int NSUB, bool APF, int WNT>
-__global__ void __launch_bounds__(256 * WNT, (WNT == 1) ? 3 : 2)
+__global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
     conv_wino_kernel(const ConvArgs p) {
     constexpr int NT = 256 * WNT;                   // 4 waves (one per transform row xi) per 32-channel n tile
     constexpr int BN = 32 * WNT;
@@ -1277,8 +1277,8 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
 namespace nd {
 // {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch,
 //  n tiles of 32 channels per block (4 waves each)}
-static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}};
-static constexpr int kNumWino = 6;
+static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3}};
+static constexpr int kNumWino = 8;
 
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1300,6 +1300,16 @@ static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
 }  // namespace nd
 
 extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
+
+extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf) {
+    if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
+    if (bm) *bm = kWinoCfg[variant][0] * 128;
+    if (bn) *bn = kWinoCfg[variant][3] * 32;
+    if (threads) *threads = kWinoCfg[variant][3] * 256;
+    if (nsub) *nsub = kWinoCfg[variant][1];
+    if (apf) *apf = kWinoCfg[variant][2];
+    return ND_OK;
+}
 
 extern "C" int64_t nd_conv_winograd_weight_floats(int N, int C) {
     if (N <= 0 || C <= 0) return ND_E_ARG;
@@ -1390,6 +1400,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         case 3: return launch_wino<1, 2, true, 2>(a, grid, lds, s);
         case 4: return launch_wino<1, 2, false, 2>(a, grid, lds, s);
         case 5: return launch_wino<1, 1, false, 1>(a, grid, lds, s);
+        case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
+        case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
     }
     return fail_arg(fn, "bad variant");
 }

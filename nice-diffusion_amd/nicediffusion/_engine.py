@@ -267,7 +267,7 @@ class UNetPlan:
         return out
 
     def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
-        """(kind, variant) for one conv launch.  Measured on the device: 3 timed launches per candidate -- every direct
+        """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct
         tile shape that fits and, for 3x3 on even sizes, the Winograd variants -- best kept and cached per shape.
         ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
         import os
@@ -285,13 +285,14 @@ class UNetPlan:
                 return None                           # this tile shape does not fit the problem
             fn(*args, stream)
             best_t = None
-            for _ in range(5):                        # min of 5 single launches: robust against clock ramps
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn(*args, stream)
+            for _ in range(2):                        # min over 2 bursts of 6 back-to-back launches: the loop being
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # tuned for runs
+                e0.record()                           # the matrix pipe continuously, where the sustained clock
+                for _ in range(6):                    # (2.0-2.15 GHz) differs from that of an isolated launch
+                    fn(*args, stream)
                 e1.record()
                 e1.synchronize()
-                t = e0.elapsed_time(e1)
+                t = e0.elapsed_time(e1) / 6
                 best_t = t if best_t is None else min(best_t, t)
             return best_t
 

@@ -1,0 +1,4 @@
+export WINO=1
+for s in "64 64 64 192 192" "64 64 64 384 384" "64 64 64 384 192" "64 32 32 384 384"; do
+  timeout -k 10 120 python tools/conv_bench.py $s 3 5,6,7 20 2>&1 | grep -E "shape|n/a"
+done
