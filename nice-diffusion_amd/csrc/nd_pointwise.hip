@@ -94,6 +94,33 @@ __global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int C, int HW,
     }
 }
 
+// image forms (ld = 4, C <= 4): one thread per pixel, the NHWC side moves as one 16-byte access, the NCHW side as C
+// plane accesses that are coalesced across the threads of a wave
+__global__ void nchw_to_nhwc4_kernel(const float* src, float* dst, int C, int HW, long npix) {
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const long img = pix / HW;
+        const int p = (int)(pix - img * HW);
+        const float* sp = src + (size_t)img * C * HW + p;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) v[c] = sp[(size_t)c * HW];
+        *reinterpret_cast<f32x4*>(dst + pix * 4) = v;
+    }
+}
+
+__global__ void nhwc4_to_nchw_kernel(const float* src, float* dst, int C, int HW, long npix) {
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const long img = pix / HW;
+        const int p = (int)(pix - img * HW);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + pix * 4);
+        float* dp = dst + (size_t)img * C * HW + p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) dp[(size_t)c * HW] = v[c];
+    }
+}
+
 // ---- direct convolution (one thread per output element; only for the non-preset stride-2 Downsample conv) -----
 __global__ void conv_direct_kernel(const float* x, int C, int ldx, const float* w, const float* bias,
                                    float* out, int ldo, int H, int W, int Ho, int Wo, int N, int ks, int stride,
@@ -133,9 +160,33 @@ __global__ void to_uint8_kernel(const float* x, int ldx, uint8_t* out, int C, in
     }
 }
 
+__device__ __forceinline__ uint32_t to_u8(float x, int invert) {
+    float v = (x + 1.0f) * 127.5f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    if (invert) v = 255.0f - v;
+    return (uint32_t)(uint8_t)v;            // truncation, as tensor.to(torch.uint8)
+}
+
+// image form (ldx = 4, C = 3 or 1, pixel count a multiple of 4): one thread per 4 pixels = 64 bytes in, 12 / 4 out
+template <int C>
+__global__ void to_uint8_pix4_kernel(const float* x, uint32_t* out, int invert, long nquads) {
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+        uint32_t b[4 * C];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (q * 4 + i) * 4);
+#pragma unroll
+            for (int c = 0; c < C; ++c) b[i * C + c] = to_u8(v[c], invert);
+        }
+#pragma unroll
+        for (int w = 0; w < C; ++w)
+            out[q * C + w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
+    }
+}
+
 static inline int grid_for(long total, int block) {
     long g = (total + block - 1) / block;
-    if (g > 4096) g = 4096;
+    if (g > 16384) g = 16384;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -191,6 +242,12 @@ extern "C" int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, i
 extern "C" int nd_nchw_to_nhwc(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream) {
     const char* fn = "nd_nchw_to_nhwc";
     ND_REQUIRE(src && dst && NI > 0 && C > 0 && HW > 0 && ld >= C, fn, "bad arguments");
+    if (ld == 4 && aligned16(dst)) {
+        const long npix = (long)NI * HW;
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C, HW,
+                           npix);
+        return check_launch(fn);
+    }
     const long total = (long)NI * HW * ld;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C,
                        HW, ld, total);
@@ -200,6 +257,12 @@ extern "C" int nd_nchw_to_nhwc(const float* src, float* dst, int NI, int C, int 
 extern "C" int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream) {
     const char* fn = "nd_nhwc_to_nchw";
     ND_REQUIRE(src && dst && NI > 0 && C > 0 && HW > 0 && ld >= C, fn, "bad arguments");
+    if (ld == 4 && aligned16(src)) {
+        const long npix = (long)NI * HW;
+        hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C, HW,
+                           npix);
+        return check_launch(fn);
+    }
     const long total = (long)NI * C * HW;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), src, dst, C,
                        HW, ld, total);
@@ -224,6 +287,17 @@ extern "C" int nd_to_uint8_hwc(const float* x, int ldx, uint8_t* out, int NI, in
                                nd_stream_t stream) {
     const char* fn = "nd_to_uint8_hwc";
     ND_REQUIRE(x && out && NI > 0 && HW > 0 && C > 0 && ldx >= C, fn, "bad arguments");
+    const long npix = (long)NI * HW;
+    if (ldx == 4 && (C == 3 || C == 1) && (npix & 3) == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+        if (C == 3)
+            hipLaunchKernelGGL(to_uint8_pix4_kernel<3>, dim3(grid_for(npix / 4, 256)), dim3(256), 0, ND_STREAM(stream), x, o32,
+                               invert, npix / 4);
+        else
+            hipLaunchKernelGGL(to_uint8_pix4_kernel<1>, dim3(grid_for(npix / 4, 256)), dim3(256), 0, ND_STREAM(stream), x, o32,
+                               invert, npix / 4);
+        return check_launch(fn);
+    }
     const long total = (long)NI * HW * C;
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out, C,
                        invert, total);

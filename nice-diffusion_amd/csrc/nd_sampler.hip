@@ -34,15 +34,23 @@ __device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t ctr_lo, ui
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
-// one N(0,1) draw for element `idx` of step `t`
-__device__ __forceinline__ float philox_normal(uint64_t seed, int t, uint64_t idx) {
+// N(0,1) draws for the two elements 2*pair and 2*pair + 1 of step `t` (Box-Muller on one Philox block)
+__device__ __forceinline__ void philox_normal_pair(uint64_t seed, int t, uint64_t pair, float& n_even, float& n_odd) {
     uint32_t r[4];
-    philox4x32_10(seed, idx >> 1, (uint64_t)(uint32_t)t, r);
+    philox4x32_10(seed, pair, (uint64_t)(uint32_t)t, r);
     const float u1 = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
     const float u2 = (float)r[1] * 2.3283064365386963e-10f;            // [0, 1)
-    const float rad = sqrtf(-2.0f * logf(u1));
+    const float rad = sqrtf(-2.0f * __logf(u1));
     const float ang = 6.283185307179586f * u2;
-    return (idx & 1) ? rad * sinf(ang) : rad * cosf(ang);
+    n_even = rad * __cosf(ang);
+    n_odd = rad * __sinf(ang);
+}
+
+// one N(0,1) draw for element `idx` of step `t`
+__device__ __forceinline__ float philox_normal(uint64_t seed, int t, uint64_t idx) {
+    float a, b;
+    philox_normal_pair(seed, t, idx >> 1, a, b);
+    return (idx & 1) ? b : a;
 }
 
 struct StepArgs {
@@ -61,71 +69,125 @@ struct StepArgs {
     long total;   // B*HW*C
 };
 
-__device__ __forceinline__ float guided_eps(const StepArgs& a, size_t pe, int c) {
-    float e = a.eps[pe + c];
-    if (a.eps_u) e = (1.0f + a.w) * e - a.w * a.eps_u[pe + c];          // diffusion.py:284 / :347
-    return e;
+__device__ __forceinline__ float mix_eps(const StepArgs& a, float e, float eu) {
+    return a.eps_u ? (1.0f + a.w) * e - a.w * eu : e;                  // diffusion.py:284 / :347
 }
 
-__global__ void __launch_bounds__(256) ddim_step_kernel(const StepArgs a) {
-    const int t = *a.step;
+// per-step scalars of the DDIM update (diffusion.py:359-360, fp32 like the reference's tensors)
+struct DdimScal {
+    float c_rec, c_recm1, s_abp, s_dir, sigma;
+};
+__device__ __forceinline__ DdimScal ddim_scalars(const StepArgs& a, int t) {
     const float* cf = a.coef + (size_t)t * ND_COEF_COLS;
-    const float c_rec = cf[0], c_recm1 = cf[1], ab = cf[2], abp = cf[3];
-    // diffusion.py:359-360, fp32 like the reference's tensors
+    const float ab = cf[2], abp = cf[3];
     const float var = a.eta * a.eta * (1.0f - abp) * (1.0f - ab / abp) / (1.0f - ab);
-    const float s_abp = sqrtf(abp);
-    const float s_dir = sqrtf(1.0f - abp - var);
-    const float sigma = (t != 0) ? sqrtf(var) : 0.0f;                  // mask = (t != 0)
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < a.total; it += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(it % a.C);
-        const long pix = it / a.C;
-        const size_t px = (size_t)pix * a.ldx + c;
-        const float xt = a.x[px];
-        const float e = guided_eps(a, (size_t)pix * a.ld_eps, c);
-        float x0 = c_rec * xt - c_recm1 * e;                             // :350-351
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                              // :353
-        float v = x0 * s_abp + s_dir * e;                                // :360
-        if (sigma != 0.0f) {
-            const float nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
-            v += sigma * nz;                                             // :366
-        }
-        a.x_out[px] = v;
+    DdimScal k;
+    k.c_rec = cf[0]; k.c_recm1 = cf[1];
+    k.s_abp = sqrtf(abp);
+    k.s_dir = sqrtf(1.0f - abp - var);
+    k.sigma = (t != 0) ? sqrtf(var) : 0.0f;                             // mask = (t != 0)
+    return k;
+}
+// one element; px = offset of the element in x / noise, it = its index in the unpadded [B][HW][C] order (Philox counter)
+__device__ __forceinline__ float ddim_elem(const DdimScal& k, float xt, float e, float nz) {
+    float x0 = k.c_rec * xt - k.c_recm1 * e;                            // :350-351
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                 // :353
+    float v = x0 * k.s_abp + k.s_dir * e;                               // :360
+    if (k.sigma != 0.0f) v += k.sigma * nz;                             // :366
+    return v;
+}
+__device__ __forceinline__ float ddpm_elem(const StepArgs& a, const float* cf, int t, float xt, float e, float lv_raw,
+                                           float nz) {
+    const float c_rec = cf[0], c_recm1 = cf[1], c_x0 = cf[4], c_xt = cf[5], lv_a = cf[6], lv_b = cf[7];
+    float log_var;
+    if (a.var_kind == ND_VAR_LEARNED) {
+        log_var = lv_raw;                                               // :249
+    } else if (a.var_kind == ND_VAR_LEARNED_INTERP) {
+        const float frac = (lv_raw + 1.0f) / 2.0f;                      // :256
+        log_var = frac * lv_b + (1.0f - frac) * lv_a;                   // :257 (max_log = lv_b, min_log = lv_a)
+    } else {
+        log_var = lv_a;                                                 // :259 / :261
     }
+    float x0 = c_rec * xt - c_recm1 * e;                                // :287-288
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                 // :290
+    float v = c_x0 * x0 + c_xt * xt;                                    // :293-294
+    if (t != 0) v += expf(0.5f * log_var) * nz;                         // :313
+    return v;
 }
 
-__global__ void __launch_bounds__(256) ddpm_step_kernel(const StepArgs a) {
+// generic form: one thread per element, any strides
+template <bool DDIM>
+__global__ void __launch_bounds__(256) step_elem_kernel(const StepArgs a) {
     const int t = *a.step;
     const float* cf = a.coef + (size_t)t * ND_COEF_COLS;
-    const float c_rec = cf[0], c_recm1 = cf[1], c_x0 = cf[4], c_xt = cf[5], lv_a = cf[6], lv_b = cf[7];
+    const DdimScal k = ddim_scalars(a, t);
+    const bool learned = !DDIM && a.var_kind != ND_VAR_FIXED;
+    const bool need_nz = DDIM ? (k.sigma != 0.0f) : (t != 0);
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < a.total; it += (long)gridDim.x * blockDim.x) {
         const int c = (int)(it % a.C);
         const long pix = it / a.C;
         const size_t px = (size_t)pix * a.ldx + c;
         const size_t pe = (size_t)pix * a.ld_eps;
         const float xt = a.x[px];
-        const float e = guided_eps(a, pe, c);
-        float log_var;
-        if (a.var_kind == ND_VAR_LEARNED) {
-            log_var = a.eps[pe + a.C + c];                               // :249
-        } else if (a.var_kind == ND_VAR_LEARNED_INTERP) {
-            const float frac = (a.eps[pe + a.C + c] + 1.0f) / 2.0f;      // :256
-            log_var = frac * lv_b + (1.0f - frac) * lv_a;                // :257 (max_log = lv_b, min_log = lv_a)
-        } else {
-            log_var = lv_a;                                              // :259 / :261
+        const float e = mix_eps(a, a.eps[pe + c], a.eps_u ? a.eps_u[pe + c] : 0.f);
+        float nz = 0.f;
+        if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
+        a.x_out[px] = DDIM ? ddim_elem(k, xt, e, nz) : ddpm_elem(a, cf, t, xt, e, learned ? a.eps[pe + a.C + c] : 0.f, nz);
+    }
+}
+
+// image form (ldx = 4, ld_eps = 4 or 8, C <= 4: every shipped configuration): one thread per pixel, 16-byte accesses;
+// same per-element arithmetic and Philox counters as the generic form
+template <bool DDIM, int C>
+__global__ void __launch_bounds__(256) step_pixel_kernel(const StepArgs a) {
+    const int t = *a.step;
+    const float* cf = a.coef + (size_t)t * ND_COEF_COLS;
+    const DdimScal k = ddim_scalars(a, t);
+    const bool learned = !DDIM && a.var_kind != ND_VAR_FIXED;
+    const bool need_nz = DDIM ? (k.sigma != 0.0f) : (t != 0);
+    const long npix = a.total / C;
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + pix * 4);
+        const float* er = a.eps + pix * a.ld_eps;
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(er);
+        f32x4 e1 = {0.f, 0.f, 0.f, 0.f}, u0 = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
+        if (a.ld_eps == 8 && learned) e1 = *reinterpret_cast<const f32x4*>(er + 4);
+        if (a.eps_u) u0 = *reinterpret_cast<const f32x4*>(a.eps_u + pix * a.ld_eps);
+        if (need_nz) {
+            if (a.noise) {
+                nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)t * a.noise_stride + pix * 4);
+            } else {
+                // the C elements of a pixel span at most two Philox pairs
+                const uint64_t it0 = (uint64_t)pix * C, p0 = it0 >> 1;
+                float g[4];
+                philox_normal_pair(a.seed, t, p0, g[0], g[1]);
+                g[2] = g[3] = 0.f;
+                if (((it0 + C - 1) >> 1) != p0) philox_normal_pair(a.seed, t, p0 + 1, g[2], g[3]);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int j = (int)(it0 + c - 2 * p0);       // 0 .. 3
+                    nz[c] = (j == 0) ? g[0] : ((j == 1) ? g[1] : ((j == 2) ? g[2] : g[3]));
+                }
+            }
         }
-        float x0 = c_rec * xt - c_recm1 * e;                             // :287-288
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                              // :290
-        float v = c_x0 * x0 + c_xt * xt;                                 // :293-294
-        if (t != 0) {
-            const float nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
-            v += expf(0.5f * log_var) * nz;                              // :313
+        f32x4 o = xv;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float e = mix_eps(a, e0[c], u0[c]);
+            const float lv = (C + c < 4) ? e0[(C + c) & 3] : e1[(C + c) & 3];
+            o[c] = DDIM ? ddim_elem(k, xv[c], e, nz[c]) : ddpm_elem(a, cf, t, xv[c], e, lv, nz[c]);
         }
-        a.x_out[px] = v;
+        *reinterpret_cast<f32x4*>(a.x_out + pix * 4) = o;
     }
 }
 
 __global__ void qsample_kernel(const float* x0, const float* noise, float* out, long n, float a, float b) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a * x0[i] + b * noise[i];
+}
+
+__global__ void qsample4_kernel(const f32x4* x0, const f32x4* noise, f32x4* out, long n4, float a, float b) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
         out[i] = a * x0[i] + b * noise[i];
 }
 
@@ -151,13 +213,31 @@ static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, 
     a.x = x; a.x_out = x_out; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
     a.noise_stride = noise_stride; a.seed = seed; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
     a.eta = eta; a.var_kind = var_kind; a.total = (long)B * HW * C;
-    long g = (a.total + 255) / 256;
-    if (g > 2048) g = 2048;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (ddim)
-        hipLaunchKernelGGL(ddim_step_kernel, dim3((int)g), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(ddpm_step_kernel, dim3((int)g), dim3(256), 0, s, a);
+    const bool image_form = ldx == 4 && (ld_eps == 4 || ld_eps == 8) && C <= 4 && aligned16(x) && aligned16(x_out) &&
+                            aligned16(eps) && (!eps_u || aligned16(eps_u)) &&
+                            (!noise || (aligned16(noise) && (noise_stride & 3) == 0));
+    if (image_form) {
+        long g = ((long)B * HW + 255) / 256;
+        if (g > 16384) g = 16384;
+#define ND_STEP_CASE(CC)                                                                                        \
+    case CC:                                                                                                    \
+        if (ddim) hipLaunchKernelGGL((step_pixel_kernel<true, CC>), dim3((int)g), dim3(256), 0, s, a);          \
+        else hipLaunchKernelGGL((step_pixel_kernel<false, CC>), dim3((int)g), dim3(256), 0, s, a);              \
+        break;
+        switch (C) {
+            ND_STEP_CASE(1)
+            ND_STEP_CASE(2)
+            ND_STEP_CASE(3)
+            ND_STEP_CASE(4)
+        }
+#undef ND_STEP_CASE
+    } else {
+        long g = (a.total + 255) / 256;
+        if (g > 8192) g = 8192;
+        if (ddim) hipLaunchKernelGGL(step_elem_kernel<true>, dim3((int)g), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(step_elem_kernel<false>, dim3((int)g), dim3(256), 0, s, a);
+    }
     return check_launch(fn);
 }
 
@@ -185,10 +265,18 @@ extern "C" int nd_qsample(const float* x0, const float* noise, float* out, int64
                           nd_stream_t stream) {
     const char* fn = "nd_qsample";
     ND_REQUIRE(x0 && noise && out && n > 0, fn, "bad arguments");
-    long g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(qsample_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x0, noise,
-                       out, (long)n, sqrt_ab, sqrt_1mab);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((n & 3) == 0 && aligned16(x0) && aligned16(noise) && aligned16(out)) {
+        long g = (n / 4 + 255) / 256;
+        if (g > 16384) g = 16384;
+        hipLaunchKernelGGL(qsample4_kernel, dim3((int)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(x0),
+                           reinterpret_cast<const f32x4*>(noise), reinterpret_cast<f32x4*>(out), (long)(n / 4), sqrt_ab,
+                           sqrt_1mab);
+    } else {
+        long g = (n + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(qsample_kernel, dim3((int)g), dim3(256), 0, s, x0, noise, out, (long)n, sqrt_ab, sqrt_1mab);
+    }
     return check_launch(fn);
 }
 

@@ -493,7 +493,48 @@ def test_philox_noise_is_standard_normal():
 
 
 def test_qsample():
-    x0, nz = rnd(2, 3, 8, 8, seed=1).to(DEV), rnd(2, 3, 8, 8, seed=2).to(DEV)
-    out = torch.empty_like(x0)
-    _hip.check(lib().nd_qsample(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), x0.numel(), 0.6, 0.8, st()))
-    assert (out - (0.6 * x0 + 0.8 * nz)).abs().max().item() < 1e-6
+    for shape in ((2, 3, 8, 8), (1, 3, 7, 5), (3, 1, 1, 1)):          # 16-byte form, scalar form (n % 4 != 0)
+        x0, nz = rnd(*shape, seed=1).to(DEV), rnd(*shape, seed=2).to(DEV)
+        out = torch.empty_like(x0)
+        _hip.check(lib().nd_qsample(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), x0.numel(), 0.6, 0.8, st()))
+        assert torch.equal(out, 0.6 * x0 + 0.8 * nz) or (out - (0.6 * x0 + 0.8 * nz)).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('ddim', [True, False])
+def test_sampler_generic_form_matches_image_form(ddim):
+    """The per-element kernel (any strides) and the per-pixel 16-byte kernel (ldx 4, ld_eps 8) share arithmetic and
+    Philox counters: same bits on the same data, with in-kernel noise."""
+    B, C, HW, S = 3, 3, 50, 6
+    x, eps = rnd(B, HW, C, seed=1), rnd(B, HW, 2 * C, seed=2, scale=0.5)
+    coef = (torch.rand(S, 8, generator=torch.Generator().manual_seed(5)) * 0.5 + 0.4).to(DEV)
+    coef[:, 3] = coef[:, 2] + 0.05                                     # abar_prev > abar
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    outs = []
+    for ldx, lde in ((4, 8), (8, 12)):
+        xd = torch.zeros(B, HW, ldx); xd[..., :C] = x
+        ed = torch.zeros(B, HW, lde); ed[..., :2 * C] = eps
+        xd, ed = xd.to(DEV), ed.to(DEV)
+        out = torch.zeros_like(xd)
+        if ddim:
+            _hip.check(lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+                                          step.data_ptr(), 0.6, None, 0, 99, B, HW, C, st()))
+        else:
+            _hip.check(lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+                                          step.data_ptr(), _hip.VAR_LEARNED_INTERP, None, 0, 99, B, HW, C, st()))
+        outs.append(out[..., :C].cpu())
+    assert torch.isfinite(outs[0]).all() and (outs[0] - x).abs().max().item() > 1e-3
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('NI,HW,C', [(3, 64, 3), (2, 49, 3), (5, 16, 1), (1, 7, 1)])
+def test_to_uint8_forms(NI, HW, C):
+    """4-pixels-per-thread form (pixel count % 4 == 0) and the per-element form, with and without inversion."""
+    x = rnd(NI, HW, C, seed=3, scale=0.8)
+    xd = torch.zeros(NI, HW, 4); xd[..., :C] = x
+    xd = xd.to(DEV)
+    for inv in (0, 1):
+        out = torch.zeros(NI * HW * C, dtype=torch.uint8, device=DEV)
+        _hip.check(lib().nd_to_uint8_hwc(xd.data_ptr(), 4, out.data_ptr(), NI, HW, C, inv, st()))
+        v = ((x + 1) * 127.5).clamp(0, 255)
+        ref = ((255 - v) if inv else v).to(torch.uint8).reshape(-1)
+        assert torch.equal(out.cpu(), ref)

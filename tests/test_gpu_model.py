@@ -172,6 +172,31 @@ def test_diffuse_matches_oracle():
         assert (got - so.diffuse(x0, steps, nz)).abs().max().item() < 1e-6
 
 
+def test_img2img_partial_chain_matches_oracle():
+    """--start_img / --steps_to_do entry (sample.py:54-64,76-78): q-sample to step k-1, then the last k reverse steps
+    (diffusion.py:133-153,192-197), DDIM and DDPM, vs the oracle on the same x_0 / noise."""
+    cfg = TINY_CFGS['adagn_updown']
+    m = build(cfg)
+    sd = m.state_dict()
+    sd = {k: v.cpu() for k, v in sd.items()}
+    torch.manual_seed(3)
+    x0, nz = torch.randn(2, 3, 16, 16).clamp(-1, 1), torch.randn(2, 3, 16, 16)
+    y = torch.tensor([1, 7])
+    for use_ddim in (True, False):
+        kw = dict(use_ddim=True, ddim_eta=0.0) if use_ddim else dict(use_ddim=False)
+        d = Diffusion(m, 1000, 10, 'learned_interpolation', 'hybrid', beta_schedule='cosine', device=DEV, **kw)
+        so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, 10, 'cosine'),
+                              'learned_interpolation', **kw)
+        for k in (1, 4, 10):
+            noises = [torch.randn(2, 3, 16, 16) for _ in range(10)]
+            xk = d.diffuse(x0, steps_to_do=k, noise=nz)
+            got = d.denoise(x=xk, kwargs={'y': y.to(DEV)}, batch_size=2, steps_to_do=k, progress=False,
+                            noise=torch.stack(noises)).cpu()
+            ref = so.denoise(so.diffuse(x0, k, nz), y, steps_to_do=k, noises=noises)
+            assert (got - ref).abs().max().item() < 1e-3, (use_ddim, k, (got - ref).abs().max().item())
+            assert got.shape == x0.shape and torch.isfinite(got).all()
+
+
 def test_weight_update_invalidates_plan():
     cfg = TINY_CFGS['adagn_updown']
     m = build(cfg)
