@@ -23,3 +23,14 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 nbytes = x.numel() * 4
 print('GN stats+apply %.3f ms; bytes read+read+write = %.1f MB -> %.2f TB/s' % (ms, 3 * nbytes / 1e6, 3 * nbytes / ms / 1e9))
+def t(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+ms = t(lambda: lib.nd_groupnorm_stats_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), NI, H * W, 32, st))
+print('   stats only %.4f ms -> %.2f TB/s (%.0f %% of 8 TB/s)' % (ms, nbytes / ms / 1e9, nbytes / ms / 1e9 / 8 * 100))
+ms = t(lambda: lib.nd_groupnorm_apply_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), g.data_ptr(), b.data_ptr(), None, None, 0, out.data_ptr(), C, NI, H, W, 32, 1e-5, 1, st))
+print('   apply only %.4f ms -> %.2f TB/s (%.0f %% of 8 TB/s)' % (ms, 2 * nbytes / ms / 1e9, 2 * nbytes / ms / 1e9 / 8 * 100))
