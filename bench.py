@@ -25,6 +25,8 @@ for p in (os.path.join(ROOT, 'nice-diffusion_amd'), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X dense fp32 (vector = matrix) peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -260,6 +262,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(model, diff, margs)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()              # the other ranks wait here while rank 0 measures the per-kernel breakdown
         dist.destroy_process_group()
 
 
