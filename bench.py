@@ -188,13 +188,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {} for --gpus {}'.format(args.gpus, args.gpus))
+    # ND_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather
+    # goes through host memory); the measured configuration is always nccl = RCCL, one rank per GPU
+    backend = os.environ.get('ND_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     margs, model, diff = build(device)
     if args.no_graph:
@@ -230,7 +238,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all()
@@ -246,7 +254,8 @@ def main():
             'config': {'workload': '64x64 conditional ImageNet UNet (OPENAI_64 preset, 296M params), {}-step DDIM '
                                    'eta=0, cosine schedule, learned_interpolation'.format(args.chain),
                        'per_gpu_batch': B, 'global_batch': Bg, 'ddim_steps_per_pass': args.chain,
-                       'parallelism': 'batch-shard x{} + all-gather'.format(world) if world > 1 else 'single GPU',
+                       'parallelism': ('batch-shard x{} + all-gather'.format(world) if world > 1 else 'single GPU') +
+                                      ('' if backend == 'nccl' else ' [REHEARSAL backend={}: not a measurement]'.format(backend)),
                        'loop': 'hipGraph replay' if diff.use_graph else 'eager'},
             'ms_per_unet_forward_plus_update': round(ms_per_step / args.chain, 3),
         }

@@ -24,6 +24,9 @@ def all_gather_rows(local, n, rank, world, group=None):
     counts = [s.stop - s.start for s in sizes]
     assert local.shape[0] == counts[rank], 'local rows {} != shard size {}'.format(local.shape[0], counts[rank])
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == 'gloo':
+        # rehearsal / test configuration only: stage through host memory (gloo has no device all-gather)
+        return all_gather_rows(local.cpu(), n, rank, world, group).to(local.device)
     if len(set(counts)) == 1:
         out = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
