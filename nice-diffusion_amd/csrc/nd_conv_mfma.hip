@@ -56,6 +56,7 @@ struct ConvArgs {
     int thl, twl, nibl;   // log2 of tile height / width / images per block
     int tiles_x, tiles_y, mt, nt;
     int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
+    int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
     int silu_out;
     // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
     const float* gnA;
@@ -925,13 +926,13 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
                     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], bfr[cur][nu][j], acc[mt][nu], 0, 0, 0);
+                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][nu][j], v[nu][j], acc[mt][nu], 0, 0, 0);
 #else
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int nu = 0; nu < 4; ++nu)
-                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][j], bfr[cur][nu][j], acc[mt][nu], 0, 0, 0);
+                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][nu][j], v[nu][j], acc[mt][nu], 0, 0, 0);
 #endif
                 }
                 if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
@@ -944,53 +945,91 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue.  r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]), exchanged through LDS:
-    //      ex[((wn*4 + xi)*2 + b)*16 + e][lane]; then wave xi finishes accumulator rows e = 4*xi .. 4*xi+3.
+    // ---- epilogue.  The MFMAs were issued as M^T = U . V^T (weights as the A operand), so in the C/D layout a lane owns
+    //      ONE Winograd tile (col = lane&31) and 4 consecutive output channels per register group.
+    //      r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]) is formed in registers and exchanged
+    //      through LDS as ex[wn][xi][b][group][lane][4]; then wave xi finishes register group xi for all four xi:
+    //      Y[a][b] = sum_xi At[a][xi] r_xi[b], i.e. 2x2 output pixels x 4 channels per lane -> 16-byte stores.
     float* ex = smem;
-    const int n = n0 + wn * 32 + l31;
-    const bool nok = n < p.N;
-    const float bvv = (nok && p.bias) ? p.bias[n] : 0.f;
+    const int nb = n0 + wn * 32 + 8 * xi + 4 * lh;          // first of this lane's 4 output channels
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (nb + c < p.N) bv[c] = p.bias[nb + c];
+    }
+    const bool vec = p.vec_ok && (nb + 3 < p.N);
 #pragma unroll
     for (int mt = 0; mt < TMW; ++mt) {
         __syncthreads();        // halo / previous round fully consumed
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float r0 = acc[mt][0][e] + acc[mt][1][e] + acc[mt][2][e];
-            const float r1 = acc[mt][1][e] - acc[mt][2][e] - acc[mt][3][e];
-            ex[(((wn * 4 + xi) * 2 + 0) * 16 + e) * 64 + lane] = r0;
-            ex[(((wn * 4 + xi) * 2 + 1) * 16 + e) * 64 + lane] = r1;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 r0, r1;
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int e = 4 * g4 + ee;
+                r0[ee] = acc[mt][0][e] + acc[mt][1][e] + acc[mt][2][e];
+                r1[ee] = acc[mt][1][e] - acc[mt][2][e] - acc[mt][3][e];
+            }
+            *reinterpret_cast<f32x4*>(ex + ((((wn * 4 + xi) * 2 + 0) * 4 + g4) * 64 + lane) * 4) = r0;
+            *reinterpret_cast<f32x4*>(ex + ((((wn * 4 + xi) * 2 + 1) * 4 + g4) * 64 + lane) * 4) = r1;
         }
         __syncthreads();
+        f32x4 rr[4][2];
 #pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const int e = 4 * xi + ee;
-            float rr[4][2];
+        for (int x2 = 0; x2 < 4; ++x2)
 #pragma unroll
-            for (int x2 = 0; x2 < 4; ++x2)
+            for (int b2 = 0; b2 < 2; ++b2)
+                rr[x2][b2] = *reinterpret_cast<const f32x4*>(ex + ((((wn * 4 + x2) * 2 + b2) * 4 + xi) * 64 + lane) * 4);
+        const int te = mt * 32 + l31;
+        const int li = te >> (thl2 + twl2);
+        const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+        const int txx = te & ((1 << twl2) - 1);
+        const int img = img0 + li;
+        if (nb < p.N && img < p.NI) {
+            f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (size_t)img * p.ld_rowbias + nb;
+                if (vec) rbv = *reinterpret_cast<const f32x4*>(rb);
+                else {
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) rr[x2][b2] = ex[(((wn * 4 + x2) * 2 + b2) * 16 + e) * 64 + lane];
-            const int te = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const int li = te >> (thl2 + twl2);
-            const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-            const int txx = te & ((1 << twl2) - 1);
-            const int img = img0 + li;
-            if (nok && img < p.NI) {
+                    for (int c = 0; c < 4; ++c)
+                        if (nb + c < p.N) rbv[c] = rb[c];
+                }
+            }
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        const float yv = (a == 0) ? (rr[0][b2] + rr[1][b2] + rr[2][b2]) : (rr[1][b2] - rr[2][b2] - rr[3][b2]);
-                        const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
-                        if (oy < p.H && ox < p.W) {
-                            float v2 = yv + bvv;
-                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + n];
-                            if (p.res) {
-                                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                           : ((size_t)(img * p.H + oy) * p.W + ox);
-                                v2 += p.res[rp * p.ldr + n];
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    f32x4 yv = (a == 0) ? (rr[0][b2] + rr[1][b2] + rr[2][b2]) : (rr[1][b2] - rr[2][b2] - rr[3][b2]);
+                    const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
+                    if (oy < p.H && ox < p.W) {
+                        yv = yv + bv;
+                        if (p.rowbias) yv += rbv;
+                        float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
+                        const float* rp = nullptr;
+                        if (p.res) {
+                            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                        : ((size_t)(img * p.H + oy) * p.W + ox);
+                            rp = p.res + rpx * p.ldr + nb;
+                        }
+                        if (vec) {
+                            if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                            if (p.silu_out) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
                             }
-                            if (p.silu_out) v2 = fast_silu(v2);
-                            p.out[((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + n] = v2;
+                            *reinterpret_cast<f32x4*>(op) = yv;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (nb + c < p.N) {
+                                    float v2 = yv[c];
+                                    if (rp) v2 += rp[c];
+                                    if (p.silu_out) v2 = fast_silu(v2);
+                                    op[c] = v2;
+                                }
+                            }
                         }
                     }
                 }
@@ -1266,6 +1305,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
+    a.vec_ok = 0;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -1420,6 +1460,9 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.mt = best.tiles_x * best.tiles_y * best.groups;
     a.nt = (N + WN * 32 - 1) / (WN * 32);
     a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float));
+    a.vec_ok = ((ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
+                (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias)))) ? 1 : 0;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {

@@ -1,5 +1,4 @@
-for s in "64 64 64 192" "64 32 32 384" "64 16 16 576" "64 8 8 768" "64 32 32 768"; do
-  for lib in gpurun_variants/libnd_gnold.so ""; do
-    echo "shape $s lib=$lib"; ND_HIP_LIB=$lib timeout -k 10 120 python tools/gn_bench.py $s 20 2>&1 | grep -v amdgpu
-  done
+export WINO=1
+for s in "64 64 64 192 192" "64 64 64 384 192" "64 32 32 384 384" "64 16 16 576 576" "64 8 8 768 768"; do
+  timeout -k 10 120 python tools/conv_bench.py $s 3 0,2,5,6,7 20 2>&1 | grep -E "shape|n/a|diff"
 done
