@@ -12,12 +12,10 @@
 //   O^T    accumulators have the query on the lane, so the online-softmax rescale is one multiply per register,
 //            and a lane owns 4 consecutive output channels per register group -> 16-byte stores.
 #include "nd_common.h"
+#include <stdlib.h>
 
 namespace nd {
 
-constexpr int AT_WAVES = 4;
-constexpr int AT_NT = AT_WAVES * 64;
-constexpr int AT_BQ = AT_WAVES * 32;   // queries per block
 constexpr int AT_KT = 64;              // keys per LDS tile
 
 struct AttnArgs {
@@ -30,9 +28,12 @@ struct AttnArgs {
 };
 
 // HDP: head dim padded to a multiple of 32 (template), hd: actual head dim (multiple of 8, <= HDP)
-template <int HDP>
-__global__ void __launch_bounds__(AT_NT)
+// WAVES = 4 or 8 waves per block (32 queries each): the K / V tile staged in LDS is shared by all of them
+template <int HDP, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
     attention_kernel(const AttnArgs p) {
+    constexpr int AT_NT = WAVES * 64;
+    constexpr int AT_BQ = WAVES * 32;      // queries per block
     constexpr int SPR = HDP / 4;           // 16-byte slots per K row
     constexpr int NC = HDP / 8;            // b128 chunks along d
     constexpr int NDT = HDP / 32;          // 32-wide d tiles of O^T
@@ -165,9 +166,10 @@ __global__ void __launch_bounds__(AT_NT)
     }
 }
 
-template <int HDP>
-static int launch_attn(const AttnArgs& a, int B, hipStream_t s) {
-    auto kern = attention_kernel<HDP>;
+template <int HDP, int WAVES>
+static int launch_attn_w(const AttnArgs& a, int B, hipStream_t s) {
+    constexpr int AT_NT = WAVES * 64, AT_BQ = WAVES * 32;
+    auto kern = attention_kernel<HDP, WAVES>;
     const size_t lds = (size_t)2 * AT_KT * HDP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
@@ -182,6 +184,26 @@ static int launch_attn(const AttnArgs& a, int B, hipStream_t s) {
     dim3 grid((a.T + AT_BQ - 1) / AT_BQ, B * a.heads);
     hipLaunchKernelGGL(kern, grid, dim3(AT_NT), lds, s, a);
     return check_launch("nd_attention_nhwc");
+}
+
+static int env_attn_waves() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("ND_ATTN_WAVES");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int HDP>
+static int launch_attn(const AttnArgs& a, int B, hipStream_t s) {
+    int w = env_attn_waves();
+    if (w != 4 && w != 8) w = (HDP <= 64 && a.T >= 512) ? 8 : 4;    // measured: +8 % at T = 1024, -7 % at T = 256
+    if (HDP > 64) w = 4;
+    if constexpr (HDP <= 64) {
+        if (w == 8) return launch_attn_w<HDP, 8>(a, B, s);
+    }
+    return launch_attn_w<HDP, 4>(a, B, s);
 }
 
 }  // namespace nd
