@@ -56,6 +56,7 @@ struct ConvArgs {
     int thl, twl, nibl;   // log2 of tile height / width / images per block
     int tiles_x, tiles_y, mt, nt;
     int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
+    int nhi;           // Winograd: halo items per thread actually needed for this tiling
     int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
     int silu_out;
     // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
@@ -706,7 +707,13 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
     constexpr int BN = 32 * WNT;
     constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
     constexpr int FRAGS = 64;
-    constexpr int MAXHI = 6;                        // halo float4 items per thread per chunk (two batches of 3)
+    // halo float4 items per thread per chunk.  The host only picks tilings with at most HPMAX halo pixels (180 for a
+    // 8x16 tile, 200 for two 8x8 images, 324 for 16x16), so a thread owns at most MAXHI of them; how many are really
+    // needed (p.nhi = ceil(HP * SPR / NT), uniform) is decided per launch, and they are fetched in two batches of HB
+    constexpr int HPMAX = (TMW == 2) ? 384 : ((WNT == 3) ? 208 : 192);
+    constexpr int MAXHI = (HPMAX * SPR + NT - 1) / NT;
+    constexpr int HB = (MAXHI + 1) / 2;
+    static_assert(MAXHI >= 2 && MAXHI <= 7, "");
     constexpr int NSTEP = 4 * NSUB;                 // k-steps (8 channels) per chunk
     static_assert(!APF || TMW == 1, "A prefetch is implemented for TMW = 1");
 
@@ -879,7 +886,7 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
         load_gn(ch + 1, gA, gB);                 // every halo fetch of this iteration is for chunk ch + 1
         int nvalid = (p.NC32 - ch * NSUB) * 4;          // k-steps of this chunk that hold real channels
         if (nvalid > NSTEP) nvalid = NSTEP;
-        f32x4 phb[3];
+        f32x4 phb[HB];
         if constexpr (APF) read_patch(hbuf, 0, 0, pa[0], pb[0]);
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
@@ -890,12 +897,17 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
                 else load_b(bfr[nxt], (ch + 1) * NSUB, 0);
                 if (st == 0 || st == NSTEP / 2) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-#if !defined(ND_WABL_NOHALO)
-                        phb[i] = load_halo_pixel(halo_next ? gpix[(st ? 3 : 0) + i] : -1, ch + 1);
+                    for (int i = 0; i < HB; ++i) {
+                        const int k = (st ? HB : 0) + i;
+                        if (k < MAXHI && k < p.nhi) {
+#if defined(ND_WABL_HALOHIT)
+                            phb[i] = load_halo_pixel(halo_next ? (gpix[k] & 1023) : -1, ch + 1);
+#elif !defined(ND_WABL_NOHALO)
+                            phb[i] = load_halo_pixel(halo_next ? gpix[k] : -1, ch + 1);
 #else
-                        phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
+                        }
                     }
                 }
                 if constexpr (APF) {
@@ -937,7 +949,14 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
                 }
                 if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) store_halo_item((st == 1 ? 0 : 3) + i, (ch + 1) & 1, phb[i]);
+                    for (int i = 0; i < HB; ++i) {
+                        const int k = (st == 1 ? 0 : HB) + i;
+#if defined(ND_WABL_NOSTORE)
+                        if (k < MAXHI && k < p.nhi) asm volatile("" :: "v"(phb[i][0]), "v"(phb[i][3]));
+#else
+                        if (k < MAXHI && k < p.nhi) store_halo_item(k, (ch + 1) & 1, phb[i]);
+#endif
+                    }
                 }
             }
         }
@@ -1305,7 +1324,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
-    a.vec_ok = 0;
+    a.vec_ok = 0; a.nhi = 0;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -1425,7 +1444,7 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     const int WM = kWinoCfg[variant][0], WN = kWinoCfg[variant][3];
     const int nsub = kWinoCfg[variant][1];
     const int nt = 256 * WN;
-    const int maxhi = 6;
+    const int hpmax = (WM == 2) ? 384 : ((WN == 3) ? 208 : 192);   // = the kernel's HPMAX
     // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
     const int bm = WM * 128;
     const int lbm = ilog2(bm);
@@ -1436,7 +1455,7 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2) * (TW + 2);
-            if ((long)hp * 8 * nsub > (long)maxhi * nt) continue;
+            if (hp > hpmax) continue;
             if ((size_t)2 * hp * 128 * nsub > 160 * 1024) continue;
             TilePlan t;
             t.thl = thl; t.twl = twl; t.nibl = nibl;
@@ -1460,6 +1479,7 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     a.mt = best.tiles_x * best.tiles_y * best.groups;
     a.nt = (N + WN * 32 - 1) / (WN * 32);
     a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float));
+    a.nhi = (best.hp * 8 * nsub + nt - 1) / nt;
     a.vec_ok = ((ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
                 (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
                 (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias)))) ? 1 : 0;

@@ -1,3 +1,4 @@
-for s in "64 1024 6 64" "64 256 9 64" "64 64 12 64"; do
-  for w in 4 8; do ND_ATTN_WAVES=$w timeout -k 10 120 python tools/attn_bench.py $s 2>&1 | grep attention; done
+export WINO=1
+for s in "64 32 32 384 384" "64 64 64 192 192" "64 16 16 576 576" "64 8 8 768 768"; do
+  timeout -k 10 120 python tools/conv_bench.py $s 3 1,2,5,6,7 20 2>&1 | grep -E "^shape|n/a"
 done
