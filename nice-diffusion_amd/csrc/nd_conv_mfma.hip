@@ -1057,6 +1057,275 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Position-split form of the Winograd kernel: 16 waves (4 per SIMD, <= 128 VGPRs), wave w owns ONE of the 16 transform
+// positions (xi = w >> 2, nu = w & 3) for all three 32-channel n tiles of a 128 px x 96 ch block.  Per k-step a wave
+// needs one transformed A fragment (4 raw ds_read_b128 + 3 vector adds instead of 8 + 8 for a whole transform row), three
+// weight fragments and 12 MFMAs; 48 accumulator registers per wave leave room for a fourth wave per SIMD to hide the
+// L2 / LDS latency the 12-wave form stalls on.  All 16 positions of a tile now live in different waves, so the output
+// transform runs through LDS for one n tile at a time (two 64 KiB exchange buffers, three rounds); the association
+// order of the sums is the one of conv_wino_kernel, so both forms give the same bits.
+template <int NSUB>
+__global__ void __launch_bounds__(1024, 4)
+    conv_wino16_kernel(const ConvArgs p) {
+    constexpr int NT = 1024, WNT = 3, BN = 96;
+    constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
+    constexpr int FRAGS = 64;
+    constexpr int HPMAX = 208;
+    constexpr int MAXHI = (HPMAX * SPR + NT - 1) / NT;      // 2 (NSUB 1) or 4 (NSUB 2)
+    constexpr int HB = (MAXHI + 1) / 2;
+    constexpr int NSTEP = 4 * NSUB;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;          // = transform position 4*xi + nu
+    const int xi = wave >> 2;
+    const int nu = wave & 3;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel
+        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
+        if (SPR == 8) return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
+        return hp * ROWF + ((slot ^ key) << 2);
+    };
+    const int hslot = tid % SPR;
+    const int hrow0 = tid / SPR;
+    int gpix[MAXHI], hoff[MAXHI];
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) {
+        const int hp = hrow0 + k * (NT / SPR);
+        int g = -1, ho = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+            ho = lds_off(hp, hy, hx, hslot);
+        }
+        gpix[k] = g;
+        hoff[k] = ho;
+    }
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
+
+    // (this form does not fold GroupNorm into the loader: the host refuses gnA for it)
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int c = ch * ROWF + (hslot << 2);
+        if (g >= 0 && c < Ctot) {
+            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        return v;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v) {
+        if (hoff[k] >= 0) *reinterpret_cast<f32x4*>(smem + buf * (HP * ROWF) + hoff[k]) = v;
+    };
+
+    // V[xi][nu] = sum_{a,b} Bt[xi][a] d[a][b] Bt[nu][b]; every row of Bt has two non-zeros (+-1):
+    //   index 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
+    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
+    const float sgr = (xi == 1) ? 1.f : -1.f;
+    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
+    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
+    const float sgc = (nu == 1) ? 1.f : -1.f;
+
+    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
+    int off4[4];          // LDS float offsets (k-step 0) of d[ra][ca], d[rb][ca], d[ra][cb], d[rb][cb] of this lane's tile
+    {
+        const int t = l31;
+        const int t_li = t >> (thl2 + twl2);
+        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
+        const int t_x = t & ((1 << twl2) - 1);
+        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
+        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
+        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
+        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
+        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
+    }
+
+    // weight fragments of this position for the three n tiles (N tail: clamped, results dropped in the epilogue)
+    const int ntile0 = nblk * WNT;
+    const float* bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
+    int noff[WNT];
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        int nt_ = ntile0 + rr;
+        if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
+        noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
+    }
+    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
+
+    f32x16 acc[WNT];
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
+
+    f32x4 bfr[2][WNT];
+    auto load_b = [&](f32x4 (&dst)[WNT], int c32, int kc) {
+        const float* qq = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
+#pragma unroll
+        for (int rr = 0; rr < WNT; ++rr) dst[rr] = *reinterpret_cast<const f32x4*>(qq + noff[rr]);
+    };
+
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k)
+        if (k < p.nhi) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
+    load_b(bfr[0], 0, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+        int nvalid = (p.NC32 - ch * NSUB) * 4;
+        if (nvalid > NSTEP) nvalid = NSTEP;
+        f32x4 phb[HB];
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st < nvalid) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < NSTEP) load_b(bfr[nxt], ch * NSUB + ((st + 1) >> 2), (st + 1) & 3);
+                else load_b(bfr[nxt], (ch + 1) * NSUB, 0);
+                if (st == 0 || st == NSTEP / 2) {
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        const int k = (st ? HB : 0) + i;
+                        if (k < MAXHI && k < p.nhi) phb[i] = load_halo_pixel(halo_next ? gpix[k] : -1, ch + 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 v;
+                {
+                    int kx = st << 3;
+                    asm volatile("" : "+s"(kx));
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
+                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
+                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
+                    const f32x4 ta = d0 + sgr * d1;          // tr[ca]
+                    const f32x4 tb = d2 + sgr * d3;          // tr[cb]
+                    v = ta + sgc * tb;
+                }
+#pragma unroll
+                for (int rr = 0; rr < WNT; ++rr)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][rr][j], v[j], acc[rr], 0, 0, 0);
+                if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        const int k = (st == 1 ? 0 : HB) + i;
+                        if (k < MAXHI && k < p.nhi) store_halo_item(k, (ch + 1) & 1, phb[i]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: three rounds (one per n tile) through two exchange buffers ex[buf][pos][group][lane][4].
+    //      Accumulators are M^T (row = channel, col = tile): register group g4 of a lane = 4 consecutive channels of its
+    //      tile.  Reader wave w finishes output pixel (a, b) = (w >> 3, (w >> 2) & 1) of channel group g4 = w & 3:
+    //      Y[a][b] = sum_xi At[a][xi] (sum_nu At[b][nu] M[xi][nu]),  At = [[1,1,1,0],[0,1,-1,-1]].
+    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
+    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
+    const int te = l31;
+    const int li = te >> (thl2 + twl2);
+    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+    const int txx = te & ((1 << twl2) - 1);
+    const int img = img0 + li;
+    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
+    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
+    __syncthreads();            // last chunk's halo fully consumed
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        {
+            // round rr+2 reuses this buffer: every wave has passed the barrier of round rr+1 by then, i.e. finished
+            // reading round rr
+            float* exw = smem + (rr & 1) * (16 * 4 * 256);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
+                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
+            }
+        }
+        __syncthreads();
+        {
+            const float* exr = smem + (rr & 1) * (16 * 4 * 256);
+            f32x4 rx[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int x2 = pa + i;
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
+                rx[i] = (m0 + sb * m1) + sb * m2;
+            }
+            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
+            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
+            if (pix_ok && nb < p.N) {
+                const bool vec = p.vec_ok && (nb + 3 < p.N);
+                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
+                const float* rp = nullptr;
+                if (p.res) {
+                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                : ((size_t)(img * p.H + oy) * p.W + ox);
+                    rp = p.res + rpx * p.ldr + nb;
+                }
+                if (vec) {
+                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
+                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
+                    if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                    if (p.silu_out) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
+                    }
+                    *reinterpret_cast<f32x4*>(op) = yv;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (nb + c < p.N) {
+                            float v2 = yv[c];
+                            if (p.bias) v2 += p.bias[nb + c];
+                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
+                            if (rp) v2 += rp[c];
+                            if (p.silu_out) v2 = fast_silu(v2);
+                            op[c] = v2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
 __global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -1374,8 +1643,10 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
 namespace nd {
 // {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch,
 //  n tiles of 32 channels per block (4 waves each)}
-static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3}};
-static constexpr int kNumWino = 8;
+static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3},
+                                 // position-split form (conv_wino16_kernel): 16 waves, 96 channels; coded as WN = 4
+                                 {1, 1, 0, 4}, {1, 2, 0, 4}};
+static constexpr int kNumWino = 10;
 
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1394,6 +1665,23 @@ static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
 
+template <int NSUB>
+static int launch_wino16(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_wino16_kernel<NSUB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return ND_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, a);
+    return check_launch("nd_conv3x3_winograd_nhwc");
+}
+
 }  // namespace nd
 
 extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
@@ -1401,8 +1689,9 @@ extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
 extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf) {
     if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
     if (bm) *bm = kWinoCfg[variant][0] * 128;
-    if (bn) *bn = kWinoCfg[variant][3] * 32;
-    if (threads) *threads = kWinoCfg[variant][3] * 256;
+    const bool split = kWinoCfg[variant][3] == 4;
+    if (bn) *bn = split ? 96 : kWinoCfg[variant][3] * 32;
+    if (threads) *threads = split ? 1024 : kWinoCfg[variant][3] * 256;
     if (nsub) *nsub = kWinoCfg[variant][1];
     if (apf) *apf = kWinoCfg[variant][2];
     return ND_OK;
@@ -1441,9 +1730,10 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const int WM = kWinoCfg[variant][0], WN = kWinoCfg[variant][3];
+    const bool split = kWinoCfg[variant][3] == 4;
+    const int WM = kWinoCfg[variant][0], WN = split ? 3 : kWinoCfg[variant][3];
     const int nsub = kWinoCfg[variant][1];
-    const int nt = 256 * WN;
+    const int nt = split ? 1024 : 256 * WN;
     const int hpmax = (WM == 2) ? 384 : ((WN == 3) ? 208 : 192);   // = the kernel's HPMAX
     // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
     const int bm = WM * 128;
@@ -1489,10 +1779,12 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1 && (ld_gn & 3) == 0 && aligned16(gnA) && aligned16(gnB), fn,
                    "fused GroupNorm: bad coefficient arrays");
         ND_REQUIRE(best.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
+        ND_REQUIRE(!split, fn, "the position-split variants do not fold GroupNorm into the loader");
     }
     const int grid = a.mt * a.nt;
     size_t lds = (size_t)2 * best.hp * 128 * nsub;
     if (lds < (size_t)WN * 32 * 1024) lds = (size_t)WN * 32 * 1024;     // epilogue exchange: 4*WN waves x 2 x 16 x 64 floats
+    if (split && lds < (size_t)128 * 1024) lds = (size_t)128 * 1024;    // two 64 KiB exchange buffers
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
         case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
@@ -1503,6 +1795,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         case 5: return launch_wino<1, 1, false, 1>(a, grid, lds, s);
         case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
+        case 8: return launch_wino16<1>(a, grid, lds, s);
+        case 9: return launch_wino16<2>(a, grid, lds, s);
     }
     return fail_arg(fn, "bad variant");
 }
