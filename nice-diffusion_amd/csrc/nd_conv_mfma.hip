@@ -1190,8 +1190,12 @@ __global__ void __launch_bounds__(1024, 4)
     f32x4 bfr[2][WNT];
     auto load_b = [&](f32x4 (&dst)[WNT], int c32, int kc) {
         const float* qq = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
+#if !defined(ND_WABL_NOB)
 #pragma unroll
         for (int rr = 0; rr < WNT; ++rr) dst[rr] = *reinterpret_cast<const f32x4*>(qq + noff[rr]);
+#else
+        asm volatile("" :: "v"(qq));
+#endif
     };
 
 #pragma unroll
@@ -1216,7 +1220,11 @@ __global__ void __launch_bounds__(1024, 4)
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
                         const int k = (st ? HB : 0) + i;
+#if !defined(ND_WABL_NOHALO)
                         if (k < MAXHI && k < p.nhi) phb[i] = load_halo_pixel(halo_next ? gpix[k] : -1, ch + 1);
+#else
+                        if (k < MAXHI && k < p.nhi) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1224,10 +1232,15 @@ __global__ void __launch_bounds__(1024, 4)
                 {
                     int kx = st << 3;
                     asm volatile("" : "+s"(kx));
+#if !defined(ND_WABL_NOA)
                     const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
                     const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
                     const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
                     const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
+#else
+                    const f32x4 d0 = f32x4{(float)(off4[0] ^ kx), 1.f, 2.f, 3.f}, d1 = f32x4{(float)(off4[1] ^ kx), 1.f, 2.f, 3.f};
+                    const f32x4 d2 = f32x4{(float)(off4[2] ^ kx), 1.f, 2.f, 3.f}, d3 = f32x4{(float)(off4[3] ^ kx), 1.f, 2.f, 3.f};
+#endif
                     const f32x4 ta = d0 + sgr * d1;          // tr[ca]
                     const f32x4 tb = d2 + sgr * d3;          // tr[cb]
                     v = ta + sgc * tb;
