@@ -57,6 +57,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, mt, nt;
     int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
     int nhi;           // Winograd: halo items per thread actually needed for this tiling
+    const float* zero; // 16 bytes of zeros in device memory (LDS-DMA source for padding)
     int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
     int silu_out;
     // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
@@ -1339,6 +1340,261 @@ __global__ void __launch_bounds__(1024, 4)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// LDS-DMA form of the position-split kernel (32-channel chunks): NOTHING is loaded into VGPRs in the main loop.
+//   * weight fragments: each is 1 KiB lane-linear in global memory, so one global_load_lds_dwordx4 drops it into a
+//     wave-private LDS ring (2 slots x 3 fragments per wave, 96 KiB per block) two k-steps ahead of its use, with no
+//     registers held while it is in flight (the register-staged form can only afford one k-step of prefetch at 128
+//     VGPRs, and its ablation shows the weight stream as the largest remaining cost);
+//   * halo: the swizzled LDS image is filled by the same instruction with the swizzle applied to the per-lane SOURCE
+//     address (the LDS side of an LDS-DMA is wave-uniform base + lane x 16 B); pixels outside the image and channels past
+//     Cin read a 16-byte zero block (the padding at the end of the packed weights).  Every wave issues exactly two
+//     halo DMAs per chunk, so all s_waitcnt vmcnt(N) below are compile-time counts.
+// LDS: [halo 2 x 32 KiB][weight ring 16 waves x 6 KiB] = 160 KiB; the epilogue exchange reuses the first 128 KiB.
+#define ND_GLDS16(gptr, lptr)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+__global__ void __launch_bounds__(1024, 4)
+    conv_wino16g_kernel(const ConvArgs p) {
+    constexpr int WNT = 3, BN = 96;
+    constexpr int ROWF = 32;
+    constexpr int FRAGS = 64;
+    constexpr int HUNITS = 2048;                 // 16-byte units per halo buffer = 2 DMAs x 16 waves x 64 lanes
+    constexpr int HBUF = HUNITS * 4;             // floats
+    constexpr int RING0 = 2 * HBUF;              // float offset of the weight ring
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;          // = transform position 4*xi + nu
+    const int xi = wave >> 2;
+    const int nu = wave & 3;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel (SPR = 8)
+        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
+        return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
+    };
+
+    // ---- halo DMA descriptors.  DMA k of this wave fills units (k*16 + wave)*64 + lane of the buffer; unit U is slot
+    //      s' = U & 15 of the 256-byte row of pixel pair U >> 4; un-swizzling gives the pixel and channel slot it holds.
+    const int Ctot = p.C0 + p.C1;
+    int gpx[2], hsl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int U = (k * 16 + wave) * 64 + lane;
+        const int pp = U >> 4;
+        const int hp0 = pp * 2;
+        int g = -1, sl = 0;
+        if (hp0 < HP) {
+            const int li = hp0 / HPI;
+            const int rem = hp0 - li * HPI;
+            const int hy = rem / HW;
+            const int hx0 = rem - hy * HW;              // even; the pair (hx0, hx0 + 1) shares the swizzle key
+            const int key = (((hy >> 1) & 3) << 2) | ((hx0 >> 1) & 3);
+            const int t = (U & 15) ^ key;
+            const int hx = hx0 + (t >> 3);
+            sl = t & 7;
+            const int img = img0 + li;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpx[k] = g;
+        hsl[k] = sl << 2;
+    }
+    const float* zero16 = p.zero;
+    auto halo_src = [&](int k, int ch) -> const float* {
+        const int c = ch * ROWF + hsl[k];
+        const int g = gpx[k];
+        const float* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
+                                      : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
+        return (g >= 0 && c < Ctot) ? src : zero16;
+    };
+    auto issue_halo = [&](int ch, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ND_GLDS16(halo_src(k, ch), smem + buf * HBUF + (k * 16 + wave) * 256);
+    };
+
+    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
+    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
+    const float sgr = (xi == 1) ? 1.f : -1.f;
+    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
+    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
+    const float sgc = (nu == 1) ? 1.f : -1.f;
+
+    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
+    int off4[4];
+    {
+        const int t = l31;
+        const int t_li = t >> (thl2 + twl2);
+        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
+        const int t_x = t & ((1 << twl2) - 1);
+        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
+        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
+        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
+        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
+        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
+    }
+
+    const int ntile0 = nblk * WNT;
+    const float* bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
+    int noff[WNT];
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        int nt_ = ntile0 + rr;
+        if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
+        noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
+    }
+    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
+    float* ring = smem + RING0 + wave * (2 * WNT * 256);      // this wave's 2 slots x 3 fragments
+    // fragments of global k-step gs = 4*c32 + kc go to ring slot gs & 1
+    auto issue_b = [&](int gs) {
+        const float* qq = bp + (size_t)(gs >> 2) * c32_stride + (gs & 3) * (16 * 256);
+#pragma unroll
+        for (int rr = 0; rr < WNT; ++rr) ND_GLDS16(qq + noff[rr], ring + ((gs & 1) * WNT + rr) * 256);
+    };
+
+    f32x16 acc[WNT];
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
+
+    const int nchunks = p.NC32;
+    issue_halo(0, 0);
+    issue_b(0);
+    issue_b(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // VMEM issue order inside chunk ch (k-steps g = 4*ch + st):   st=0: B(g+2), H(ch+1) x2;  st=1..3: B(g+2).
+    // Before reading B(g) (issued two steps earlier) the younger operations allowed in flight are B(g+1) and whatever was
+    // issued between them:  st=0: 3;  st=1: 3 + 2 halo;  st=2: 2 halo + 3;  st=3: 3.
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * HBUF;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int gs = ch * 4 + st;
+            if (st == 0 || st == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            f32x4 bfr[WNT];
+#pragma unroll
+            for (int rr = 0; rr < WNT; ++rr)
+                bfr[rr] = *reinterpret_cast<const f32x4*>(ring + ((st & 1) * WNT + rr) * 256 + lane * 4);
+            const int kx = st << 3;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
+            const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot (gs & 1) has been read: refill it
+            issue_b(gs + 2);
+            if (st == 0) issue_halo(ch + 1, (ch + 1) & 1);          // past the last chunk: zero block (c >= Ctot)
+            const f32x4 ta = d0 + sgr * d1;
+            const f32x4 tb = d2 + sgr * d3;
+            const f32x4 v = ta + sgc * tb;
+#pragma unroll
+            for (int rr = 0; rr < WNT; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[rr][j], v[j], acc[rr], 0, 0, 0);
+        }
+        // next chunk's halo (issued at st = 0, followed by 9 weight DMAs) must have landed before anyone reads it
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // run-ahead weight DMAs still target the ring
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: identical to conv_wino16_kernel
+    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
+    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
+    const int te = l31;
+    const int li = te >> (thl2 + twl2);
+    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+    const int txx = te & ((1 << twl2) - 1);
+    const int img = img0 + li;
+    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
+    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        {
+            float* exw = smem + (rr & 1) * (16 * 4 * 256);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
+                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
+            }
+        }
+        __syncthreads();
+        {
+            const float* exr = smem + (rr & 1) * (16 * 4 * 256);
+            f32x4 rx[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int x2 = pa + i;
+                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
+                rx[i] = (m0 + sb * m1) + sb * m2;
+            }
+            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
+            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
+            if (pix_ok && nb < p.N) {
+                const bool vec = p.vec_ok && (nb + 3 < p.N);
+                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
+                const float* rp = nullptr;
+                if (p.res) {
+                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                : ((size_t)(img * p.H + oy) * p.W + ox);
+                    rp = p.res + rpx * p.ldr + nb;
+                }
+                if (vec) {
+                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
+                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
+                    if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                    if (p.silu_out) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
+                    }
+                    *reinterpret_cast<f32x4*>(op) = yv;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (nb + c < p.N) {
+                            float v2 = yv[c];
+                            if (p.bias) v2 += p.bias[nb + c];
+                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
+                            if (rp) v2 += rp[c];
+                            if (p.silu_out) v2 = fast_silu(v2);
+                            op[c] = v2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
 __global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -1606,7 +1862,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
-    a.vec_ok = 0; a.nhi = 0;
+    a.vec_ok = 0; a.nhi = 0; a.zero = nullptr;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -1658,8 +1914,10 @@ namespace nd {
 //  n tiles of 32 channels per block (4 waves each)}
 static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3},
                                  // position-split form (conv_wino16_kernel): 16 waves, 96 channels; coded as WN = 4
-                                 {1, 1, 0, 4}, {1, 2, 0, 4}};
-static constexpr int kNumWino = 10;
+                                 {1, 1, 0, 4}, {1, 2, 0, 4},
+                                 // + LDS-DMA operand streams (conv_wino16g_kernel); coded as WN = 5
+                                 {1, 1, 0, 5}};
+static constexpr int kNumWino = 11;
 
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1702,7 +1960,7 @@ extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
 extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf) {
     if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
     if (bm) *bm = kWinoCfg[variant][0] * 128;
-    const bool split = kWinoCfg[variant][3] == 4;
+    const bool split = kWinoCfg[variant][3] >= 4;
     if (bn) *bn = split ? 96 : kWinoCfg[variant][3] * 32;
     if (threads) *threads = split ? 1024 : kWinoCfg[variant][3] * 256;
     if (nsub) *nsub = kWinoCfg[variant][1];
@@ -1743,7 +2001,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const bool split = kWinoCfg[variant][3] == 4;
+    const bool split = kWinoCfg[variant][3] >= 4;
+    const bool dma = kWinoCfg[variant][3] == 5;
     const int WM = kWinoCfg[variant][0], WN = split ? 3 : kWinoCfg[variant][3];
     const int nsub = kWinoCfg[variant][1];
     const int nt = split ? 1024 : 256 * WN;
@@ -1798,6 +2057,8 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     size_t lds = (size_t)2 * best.hp * 128 * nsub;
     if (lds < (size_t)WN * 32 * 1024) lds = (size_t)WN * 32 * 1024;     // epilogue exchange: 4*WN waves x 2 x 16 x 64 floats
     if (split && lds < (size_t)128 * 1024) lds = (size_t)128 * 1024;    // two 64 KiB exchange buffers
+    if (dma) lds = (size_t)160 * 1024;
+    a.zero = w + (nd_conv_winograd_weight_floats(N, C0 + C1) - 256);     // inside the zero padding block
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
         case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
@@ -1810,6 +2071,20 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
         case 9: return launch_wino16<2>(a, grid, lds, s);
+        case 10: {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16g_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) {
+                    set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    return ND_E_LAUNCH;
+                }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(conv_wino16g_kernel, dim3(grid), dim3(1024), lds, s, a);
+            return check_launch(fn);
+        }
     }
     return fail_arg(fn, "bad variant");
 }
