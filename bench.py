@@ -101,9 +101,8 @@ def roofline_from(rows, lib):
     if kind == 'wino':
         bm, bn, nt, nsub, apf = (ctypes.c_int() for _ in range(5))
         lib.nd_conv_winograd_variant_info(var, *(ctypes.byref(v) for v in (bm, bn, nt, nsub, apf)))
-        kname = ('nd::conv_wino_kernel<{}, {}, {}, {}> (Winograd F(2x2,3x3) on fp32 MFMA; {} px x {} ch per block, '
-                 '{} threads)').format(bm.value // 128, nsub.value, 'true' if apf.value else 'false', bn.value // 32,
-                                       bm.value, bn.value, nt.value)
+        kname = '{} (Winograd F(2x2,3x3) on fp32 MFMA; {} px x {} ch per block, {} threads)'.format(
+            lib.nd_conv_winograd_variant_name(var).decode(), bm.value, bn.value, nt.value)
         executed = 4.0 / 9.0
     else:
         bm, bn, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

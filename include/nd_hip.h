@@ -94,6 +94,8 @@ int nd_conv_winograd_num_variants(void);
 /* A Winograd variant's block shape: output pixels and output channels per block, threads, 32-channel sub-chunks per LDS
  * chunk and whether the A operand is prefetched (the kernel's template arguments; used by bench.py to name kernels). */
 int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf);
+/* The variant's kernel as a profiler prints it, e.g. "nd::conv_wino16_kernel<1>" ("" for a bad variant). */
+const char* nd_conv_winograd_variant_name(int variant);
 int64_t nd_conv_winograd_weight_floats(int N, int C);
 int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream);
 int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,

@@ -1914,10 +1914,10 @@ namespace nd {
 //  n tiles of 32 channels per block (4 waves each)}
 static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3},
                                  // position-split form (conv_wino16_kernel): 16 waves, 96 channels; coded as WN = 4
-                                 {1, 1, 0, 4}, {1, 2, 0, 4},
+                                 {1, 1, 0, 4},
                                  // + LDS-DMA operand streams (conv_wino16g_kernel); coded as WN = 5
                                  {1, 1, 0, 5}};
-static constexpr int kNumWino = 11;
+static constexpr int kNumWino = 10;
 
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1956,6 +1956,16 @@ static int launch_wino16(const ConvArgs& a, int grid, size_t lds, hipStream_t s)
 }  // namespace nd
 
 extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
+
+extern "C" const char* nd_conv_winograd_variant_name(int variant) {
+    static const char* names[] = {"nd::conv_wino_kernel<2, 1, false, 2>", "nd::conv_wino_kernel<1, 1, false, 2>",
+                                  "nd::conv_wino_kernel<1, 1, true, 2>",  "nd::conv_wino_kernel<1, 2, true, 2>",
+                                  "nd::conv_wino_kernel<1, 2, false, 2>", "nd::conv_wino_kernel<1, 1, false, 1>",
+                                  "nd::conv_wino_kernel<1, 2, false, 3>", "nd::conv_wino_kernel<1, 1, false, 3>",
+                                  "nd::conv_wino16_kernel<1>",            "nd::conv_wino16g_kernel"};
+    static_assert(sizeof(names) / sizeof(names[0]) == kNumWino, "one name per variant");
+    return (variant < 0 || variant >= kNumWino) ? "" : names[variant];
+}
 
 extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf) {
     if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
@@ -2070,8 +2080,7 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
-        case 9: return launch_wino16<2>(a, grid, lds, s);
-        case 10: {
+        case 9: {
             static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16g_kernel),

@@ -61,6 +61,7 @@ _SPECIAL = {
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_winograd_variant_info': ([_i] + [ctypes.POINTER(_i)] * 5, _i),
+    'nd_conv_winograd_variant_name': ([_i], ctypes.c_char_p),
     'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),
     'nd_conv_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_last_error': ([], ctypes.c_char_p),
