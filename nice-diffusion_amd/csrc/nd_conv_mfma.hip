@@ -1247,10 +1247,11 @@ __global__ void __launch_bounds__(1024, 4)
                     v = ta + sgc * tb;
                 }
 #pragma unroll
-                for (int rr = 0; rr < WNT; ++rr)
+                for (int rr = 0; rr < WNT; ++rr) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][rr][j], v[j], acc[rr], 0, 0, 0);
+                }
                 if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
@@ -1507,16 +1508,17 @@ __global__ void __launch_bounds__(1024, 4)
             const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
             const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot (gs & 1) has been read: refill it
-            issue_b(gs + 2);
+            issue_b(gs + 2);                                       // (a partial lgkmcnt(4) here measured 10 % slower)
             if (st == 0) issue_halo(ch + 1, (ch + 1) & 1);          // past the last chunk: zero block (c >= Ctot)
             const f32x4 ta = d0 + sgr * d1;
             const f32x4 tb = d2 + sgr * d3;
             const f32x4 v = ta + sgc * tb;
 #pragma unroll
-            for (int rr = 0; rr < WNT; ++rr)
+            for (int rr = 0; rr < WNT; ++rr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[rr][j], v[j], acc[rr], 0, 0, 0);
+            }
         }
         // next chunk's halo (issued at st = 0, followed by 9 weight DMAs) must have landed before anyone reads it
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
