@@ -91,6 +91,18 @@ int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);
  * H and W must be even; `w` must come from nd_repack_conv_weight_winograd (nd_conv_winograd_weight_floats floats);
  * `variant` in [0, nd_conv_winograd_num_variants()).  Callers pick direct vs Winograd per shape by measurement. */
 int nd_conv_winograd_num_variants(void);
+/* The same convolution by the position-split kernel (variant nd_conv_winograd_stats_variant()) which, besides the
+ * output, leaves PARTIAL statistics of it behind: pstats[img][mb][q][0|1][n] = sum | sum of squares of out[img][.][.][n]
+ * over the pixels that m block mb (of *mbi per image) and pixel-wave q (of 4) produced -- plain stores, every entry is
+ * written by every launch (no zeroing, no atomics); nd_conv_winograd_stats_floats gives the size and *mbi.  ldo must
+ * equal N.  nd_groupnorm_stats_from_partials folds them into the per-group statistics of the next GroupNorm, which
+ * therefore needs no pass over the tensor. */
+int nd_conv_winograd_stats_variant(void);
+int64_t nd_conv_winograd_stats_floats(int NI, int H, int W, int N, int* mbi);
+int nd_conv3x3_winograd_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                   const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                   const float* residual, int ldr, float* out, int ldo,
+                                   int NI, int H, int W, int N, int flags, float* pstats, nd_stream_t stream);
 /* A Winograd variant's block shape: output pixels and output channels per block, threads, 32-channel sub-chunks per LDS
  * chunk and whether the A operand is prefetched (the kernel's template arguments; used by bench.py to name kernels). */
 int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf);
@@ -127,6 +139,11 @@ int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int k
 int nd_groupnorm_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, double* stats, int NI, int HW, int G,
                             nd_stream_t stream);
+/* Partial output statistics written by nd_conv3x3_winograd_stats_nhwc (p0: rows0 = mbi*4 partial rows per image over C0
+ * channels; optionally concatenated with p1 over C1 channels) -> ADDS the per-group sums to stats [NI][G][2], the
+ * array nd_groupnorm_stats_nhwc fills (caller zeroes it, as for that function). */
+int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
+                                     double* stats, int NI, int G, nd_stream_t stream);
 /* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions
  * that apply it while loading their input (gnA/gnB of nd_conv_nhwc / nd_conv3x3_winograd_nhwc). */
 int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,

@@ -77,6 +77,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         const int key0 = kt * AT_KT;
         __syncthreads();   // previous tile fully consumed
         // ---- stage K and V tiles (zero-filled beyond T / hd)
+#if defined(ND_AABL_NOLOAD)
+        if (kt == 0)
+#endif
         for (int it = tid; it < AT_KT * SPR; it += AT_NT) {
             const int row = it / SPR;
             const int sl = it - row * SPR;

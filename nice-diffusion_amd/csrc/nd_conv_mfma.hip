@@ -58,6 +58,8 @@ struct ConvArgs {
     int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
     int nhi;           // Winograd: halo items per thread actually needed for this tiling
     const float* zero; // 16 bytes of zeros in device memory (LDS-DMA source for padding)
+    float* chstats;    // optional partial output statistics [NI][mbi][4][2][N] (see conv_wino16_kernel's epilogue)
+    int mbi;           // m blocks per image (1 when a block holds whole images)
     int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
     int silu_out;
     // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
@@ -1305,6 +1307,7 @@ __global__ void __launch_bounds__(1024, 4)
             }
             f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
             const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
+            f32x4 fin = {0.f, 0.f, 0.f, 0.f};          // what was stored (zeros for lanes / channels that store nothing)
             if (pix_ok && nb < p.N) {
                 const bool vec = p.vec_ok && (nb + 3 < p.N);
                 float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
@@ -1323,6 +1326,7 @@ __global__ void __launch_bounds__(1024, 4)
                         for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
                     }
                     *reinterpret_cast<f32x4*>(op) = yv;
+                    fin = yv;
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -1333,6 +1337,38 @@ __global__ void __launch_bounds__(1024, 4)
                             if (rp) v2 += rp[c];
                             if (p.silu_out) v2 = fast_silu(v2);
                             op[c] = v2;
+                            fin[c] = v2;
+                        }
+                    }
+                }
+            }
+            if (p.chstats) {
+                // GroupNorm statistics of the output for free: per-channel sum / sum of squares over this wave's pixels of
+                // each image (the tiles of one image are a power-of-two run of lanes), stored as one partial row per
+                // (image, m block, pixel-wave): no atomics, and the consumer reads N floats x 8 x m-blocks per image
+                // instead of the whole tensor.
+                f32x4 sq = fin * fin;
+                const int gl = 1 << (thl2 + twl2);          // tiles (= lanes of a half-wave) per image
+                for (int m = 1; m < gl; m <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        fin[c] += __shfl_xor(fin[c], m);
+                        sq[c] += __shfl_xor(sq[c], m);
+                    }
+                }
+                if ((l31 & (gl - 1)) == 0 && img < p.NI && nb < p.N) {
+                    const int mb = (p.nibl == 0) ? (ty * p.tiles_x + tx) : 0;
+                    float* ps = p.chstats + ((((size_t)img * p.mbi + mb) * 4 + (wave >> 2)) * 2) * p.N + nb;
+                    if (nb + 3 < p.N && (p.N & 3) == 0) {
+                        *reinterpret_cast<f32x4*>(ps) = fin;
+                        *reinterpret_cast<f32x4*>(ps + p.N) = sq;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (nb + c < p.N) {
+                                ps[c] = fin[c];
+                                ps[p.N + c] = sq[c];
+                            }
                         }
                     }
                 }
@@ -1341,17 +1377,6 @@ __global__ void __launch_bounds__(1024, 4)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// LDS-DMA form of the position-split kernel (32-channel chunks): NOTHING is loaded into VGPRs in the main loop.
-//   * weight fragments: each is 1 KiB lane-linear in global memory, so one global_load_lds_dwordx4 drops it into a
-//     wave-private LDS ring (2 slots x 3 fragments per wave, 96 KiB per block) two k-steps ahead of its use, with no
-//     registers held while it is in flight (the register-staged form can only afford one k-step of prefetch at 128
-//     VGPRs, and its ablation shows the weight stream as the largest remaining cost);
-//   * halo: the swizzled LDS image is filled by the same instruction with the swizzle applied to the per-lane SOURCE
-//     address (the LDS side of an LDS-DMA is wave-uniform base + lane x 16 B); pixels outside the image and channels past
-//     Cin read a 16-byte zero block (the padding at the end of the packed weights).  Every wave issues exactly two
-//     halo DMAs per chunk, so all s_waitcnt vmcnt(N) below are compile-time counts.
-// LDS: [halo 2 x 32 KiB][weight ring 16 waves x 6 KiB] = 160 KiB; the epilogue exchange reuses the first 128 KiB.
 #define ND_GLDS16(gptr, lptr)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -1864,7 +1889,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
-    a.vec_ok = 0; a.nhi = 0; a.zero = nullptr;
+    a.vec_ok = 0; a.nhi = 0; a.zero = nullptr; a.chstats = nullptr; a.mbi = 1;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -1920,6 +1945,7 @@ static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 
                                  // + LDS-DMA operand streams (conv_wino16g_kernel); coded as WN = 5
                                  {1, 1, 0, 5}};
 static constexpr int kNumWino = 10;
+static constexpr int kStatsVariant = 8;        // conv_wino16_kernel: the one whose epilogue can emit output statistics
 
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1996,30 +2022,9 @@ extern "C" int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out,
     return check_launch(fn);
 }
 
-extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
-                                        const float* residual, int ldr, float* out, int ldo,
-                                        int NI, int H, int W, int N, int flags, int variant,
-                                        const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
-    const char* fn = "nd_conv3x3_winograd_nhwc";
-    ND_REQUIRE(x0 && w && out, fn, "null pointer");
-    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
-    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "Winograd F(2x2,3x3) needs even H and W");
-    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && ldo >= N, fn, "channels / strides");
-    ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
-    if (C1 > 0) ND_REQUIRE(x1 != nullptr && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn, "x1");
-    if (flags & ND_CONV_SILU_OUT) ND_REQUIRE(residual == nullptr, fn, "SILU_OUT with a residual is not supported");
-    if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
-    if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
-    ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
-    ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const bool split = kWinoCfg[variant][3] >= 4;
-    const bool dma = kWinoCfg[variant][3] == 5;
-    const int WM = kWinoCfg[variant][0], WN = split ? 3 : kWinoCfg[variant][3];
-    const int nsub = kWinoCfg[variant][1];
-    const int nt = split ? 1024 : 256 * WN;
-    const int hpmax = (WM == 2) ? 384 : ((WN == 3) ? 208 : 192);   // = the kernel's HPMAX
-    // block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2
+// Winograd block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2: fewest padded pixels,
+// then smallest halo
+static bool wino_tiles(int WM, int nsub, int hpmax, int NI, int H, int W, TilePlan* out) {
     const int bm = WM * 128;
     const int lbm = ilog2(bm);
     TilePlan best{};
@@ -2039,6 +2044,35 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
             if (!found || t.padded < best.padded || (t.padded == best.padded && t.hp < best.hp)) { best = t; found = true; }
         }
     }
+    if (found) *out = best;
+    return found;
+}
+
+static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                       const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                       const float* residual, int ldr, float* out, int ldo,
+                       int NI, int H, int W, int N, int flags, int variant,
+                       const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream) {
+    const char* fn = "nd_conv3x3_winograd_nhwc";
+    ND_REQUIRE(x0 && w && out, fn, "null pointer");
+    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
+    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "Winograd F(2x2,3x3) needs even H and W");
+    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && ldo >= N, fn, "channels / strides");
+    ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
+    if (C1 > 0) ND_REQUIRE(x1 != nullptr && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn, "x1");
+    if (flags & ND_CONV_SILU_OUT) ND_REQUIRE(residual == nullptr, fn, "SILU_OUT with a residual is not supported");
+    if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
+    if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
+    ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
+    ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
+    const bool split = kWinoCfg[variant][3] >= 4;
+    const bool dma = kWinoCfg[variant][3] == 5;
+    const int WM = kWinoCfg[variant][0], WN = split ? 3 : kWinoCfg[variant][3];
+    const int nsub = kWinoCfg[variant][1];
+    const int nt = split ? 1024 : 256 * WN;
+    const int hpmax = (WM == 2) ? 384 : ((WN == 3) ? 208 : 192);   // = the kernel's HPMAX
+    TilePlan best{};
+    const bool found = wino_tiles(WM, nsub, hpmax, NI, H, W, &best);
     if (!found) return fail_arg(fn, "no tiling fits this shape");
     const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
     ConvArgs a;
@@ -2071,6 +2105,9 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
     if (split && lds < (size_t)128 * 1024) lds = (size_t)128 * 1024;    // two 64 KiB exchange buffers
     if (dma) lds = (size_t)160 * 1024;
     a.zero = w + (nd_conv_winograd_weight_floats(N, C0 + C1) - 256);     // inside the zero padding block
+    a.chstats = chstats;
+    a.mbi = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
+    if (chstats) ND_REQUIRE(variant == kStatsVariant && ldo == N, fn, "output statistics: only the position-split variant produces them (and needs ldo == N)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
         case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
@@ -2098,4 +2135,34 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
         }
     }
     return fail_arg(fn, "bad variant");
+}
+
+extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                        const float* residual, int ldr, float* out, int ldo,
+                                        int NI, int H, int W, int N, int flags, int variant,
+                                        const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
+    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
+                       flags, variant, gnA, gnB, ld_gn, nullptr, stream);
+}
+
+extern "C" int nd_conv_winograd_stats_variant(void) { return kStatsVariant; }
+
+extern "C" int64_t nd_conv_winograd_stats_floats(int NI, int H, int W, int N, int* mbi) {
+    if (NI <= 0 || H <= 0 || W <= 0 || N <= 0 || (H & 1) || (W & 1)) return ND_E_ARG;
+    TilePlan best{};
+    if (!wino_tiles(1, 1, 208, NI, H, W, &best)) return ND_E_ARG;
+    const int m = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
+    if (mbi) *mbi = m;
+    return (int64_t)NI * m * 8 * N;
+}
+
+extern "C" int nd_conv3x3_winograd_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                              const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                              const float* residual, int ldr, float* out, int ldo,
+                                              int NI, int H, int W, int N, int flags,
+                                              float* chstats, nd_stream_t stream) {
+    if (!chstats) return fail_arg("nd_conv3x3_winograd_stats_nhwc", "chstats is null");
+    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
+                       flags, kStatsVariant, nullptr, nullptr, 0, chstats, stream);
 }

@@ -214,6 +214,56 @@ static int check_src(const char* fn, const float* x0, int C0, int ldx0, const fl
     return ND_OK;
 }
 
+// partial rows [img][row][0|1][C] (sum | sum of squares per channel) of a (two-source) tensor -> per-(image, group) sums
+// in float64, added to the array gn_stats_kernel fills.  grid (NI, 2 sources); one block per image and source.
+__global__ void __launch_bounds__(256)
+    gn_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, double* stats, int G) {
+    __shared__ double sh[2 * 64];          // [G][2], G <= 64
+    const int img = blockIdx.x;
+    const int src = blockIdx.y;
+    const float* pp = src ? p1 : p0;
+    const int Cs = src ? C1 : C0, rows_all = src ? rows1 : rows0, cbase = src ? C0 : 0;
+    // blockIdx.z splits the rows
+    const int rchunk = (rows_all + gridDim.z - 1) / gridDim.z;
+    const int rbeg = blockIdx.z * rchunk;
+    const int rows = (rbeg + rchunk < rows_all) ? rbeg + rchunk : rows_all;   // end (exclusive)
+    if (rbeg >= rows) return;
+    const int cpg = (C0 + C1) / G;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sh[i] = 0.0;
+    __syncthreads();
+    // thread t owns channel c = t % Cs (fixed group) and walks the rows t / Cs, t / Cs + blockDim.x / Cs, ...
+    if (Cs <= (int)blockDim.x) {
+        const int per = blockDim.x / Cs;
+        const int c = threadIdx.x % Cs, r0 = threadIdx.x / Cs;
+        if (r0 < per) {
+            double a = 0.0, b = 0.0;
+            for (int r = rbeg + r0; r < rows; r += per) {
+                const float* q = pp + (((size_t)img * rows_all + r) * 2) * Cs + c;
+                a += (double)q[0];
+                b += (double)q[Cs];
+            }
+            const int g = (cbase + c) / cpg;
+            atomicAdd(&sh[2 * g], a);
+            atomicAdd(&sh[2 * g + 1], b);
+        }
+    } else {
+        for (int c = threadIdx.x; c < Cs; c += blockDim.x) {
+            double a = 0.0, b = 0.0;
+            for (int r = rbeg; r < rows; ++r) {
+                const float* q = pp + (((size_t)img * rows_all + r) * 2) * Cs + c;
+                a += (double)q[0];
+                b += (double)q[Cs];
+            }
+            const int g = (cbase + c) / cpg;
+            atomicAdd(&sh[2 * g], a);
+            atomicAdd(&sh[2 * g + 1], b);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x)
+        if (sh[i] != 0.0) atomicAdd(&stats[(size_t)img * G * 2 + i], sh[i]);
+}
+
 }  // namespace nd
 
 using namespace nd;
@@ -285,5 +335,20 @@ extern "C" int nd_groupnorm_coeffs(const double* stats, const float* gamma, cons
     ND_REQUIRE((scale == nullptr) == (shift == nullptr) && ld_coef >= C, fn, "scale/shift go together; ld_coef >= C");
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3((C + 127) / 128, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
                        stats, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef, C, HW, G, eps);
+    return check_launch(fn);
+}
+
+extern "C" int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
+                                               double* stats, int NI, int G, nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_stats_from_partials";
+    ND_REQUIRE(p0 && stats && NI > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 64 && (C0 + C1) % G == 0, fn,
+               "bad arguments");
+    if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
+    const int rmax = rows0 > rows1 ? rows0 : rows1;
+    int splits = rmax / 8;
+    if (splits < 1) splits = 1;
+    if (splits > 16) splits = 16;
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(NI, C1 > 0 ? 2 : 1, splits), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), p0, C0, rows0, C1 > 0 ? p1 : p0, C1, rows1, stats, G);
     return check_launch(fn);
 }

@@ -56,11 +56,12 @@ def _pad4(n):
 
 class Act:
     """NHWC activation: flat fp32 buffer + geometry."""
-    __slots__ = ('t', 'NI', 'H', 'W', 'C', 'ld')
+    __slots__ = ('t', 'NI', 'H', 'W', 'C', 'ld', 'cs')
 
     def __init__(self, t, NI, H, W, C, ld=None):
         self.t, self.NI, self.H, self.W, self.C = t, NI, H, W, C
         self.ld = C if ld is None else ld
+        self.cs = None      # (('chpart', float offset), rows per image): partial output statistics left by the producing conv
 
     @property
     def ptr(self):
@@ -75,6 +76,15 @@ class Normed:
     def __init__(self, **kw):
         for k, v in kw.items():
             setattr(self, k, v)
+
+
+def _epilogue_stats_enabled():
+    """ND_GN_EPILOGUE_STATS=1: let the position-split Winograd convs leave partial GroupNorm statistics of their output
+    behind (nd_conv3x3_winograd_stats_nhwc + nd_groupnorm_stats_from_partials) instead of a statistics pass over the
+    tensor.  Off by default: measured at B=64 it removes 1.0 ms of HBM-bound statistics kernels but the cross-lane
+    reduction in the epilogue costs the MFMA-bound convs 2.2 ms (forward 76.8 vs 75.6 ms)."""
+    import os
+    return os.environ.get('ND_GN_EPILOGUE_STATS', '0') == '1'
 
 
 def _fuse_gn_mode():
@@ -145,6 +155,7 @@ class UNetPlan:
         self.out = torch.empty(NI * R * R * self.Cout_p, **f32)
         self._gn_slots = 0
         self._gn_users = []     # ops needing the stats base pointer patched in
+        self._cs_floats = 0     # fp32 words of partial output statistics (see conv(want_stats=True))
         _load_tune_cache()
         n_tuned = len(_TUNED)
         self._build()
@@ -203,7 +214,7 @@ class UNetPlan:
         return out
 
     def conv(self, src, weight, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
-             residual=None, flags=0, label='conv', pad_c_to=None):
+             residual=None, flags=0, label='conv', pad_c_to=None, want_stats=False):
         """Emit one convolution.  ``src`` (and optional ``src2``, concatenated after it) are Acts; ``weight`` is the
         module's parameter (packed here); output spatial size is src's, doubled when CONV_IN_UP2X is set.  For 3x3
         convolutions on even sizes the Winograd F(2x2,3x3) kernel competes with the direct kernel's tile shapes and
@@ -246,8 +257,21 @@ class UNetPlan:
             wq = self._packed_wino(weight, pad_c_to)
             self.keep.append(wq)
             self.packed_floats += wq.numel()
-            self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var] + gn, label,
-                       flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+            if (want_stats and _epilogue_stats_enabled() and var == self.lib.nd_conv_winograd_stats_variant()
+                    and gn[0] is None and out.ld == N):
+                # the position-split kernel leaves the next GroupNorm's statistics behind (no extra pass over `out`)
+                import ctypes
+                mbi = ctypes.c_int()
+                nfl = self.lib.nd_conv_winograd_stats_floats(NI, H, W, N, ctypes.byref(mbi))
+                assert nfl > 0
+                ph = ('chpart', self._cs_floats)
+                out.cs = (ph, mbi.value * 4)
+                self._cs_floats += (nfl + 3) // 4 * 4
+                self._emit(self.lib.nd_conv3x3_winograd_stats_nhwc, head + [wq.data_ptr()] + tail + [flags, ph], label,
+                           flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+            else:
+                self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var] + gn, label,
+                           flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         else:
             wp = self._packed(weight, pad_c_to)
             self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var] + gn, label, flops=fl,
@@ -346,8 +370,13 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
-        stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS]
-        self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
+        if src.cs is not None and (src2 is None or src2.cs is not None):
+            self._emit(self.lib.nd_groupnorm_stats_from_partials,
+                       [src.cs[0], src.C, src.cs[1], None if src2 is None else src2.cs[0], 0 if src2 is None else src2.C,
+                        0 if src2 is None else src2.cs[1], ('gnstats', slot), NI, GN_GROUPS], label + '.stats_from_partials')
+        else:
+            stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS]
+            self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
         if pool:
             out = self._new(NI, H // 2, W // 2, C)
             flags = (_hip.GN_SILU if silu else 0) | _hip.GN_POOL2
@@ -427,14 +456,23 @@ class UNetPlan:
         self._release(x_cur)
 
         # ---- GroupNorm statistics arena (float64 [slots][NI][32][2]); zeroed at the start of every run
-        self.gn_stats = torch.zeros(max(1, self._gn_slots) * NI * GN_GROUPS * 2, dtype=torch.float64, device=dev)
+        n_gn = max(1, self._gn_slots) * NI * GN_GROUPS * 2
+        self.gn_stats = torch.zeros(n_gn, dtype=torch.float64, device=dev)
         slot_bytes = NI * GN_GROUPS * 2 * 8
         base = self.gn_stats.data_ptr()
+        # partial output statistics written by the position-split convs (fully rewritten every forward)
+        self.ch_partials = torch.zeros(max(4, self._cs_floats), dtype=torch.float32, device=dev)
+        cs_base = self.ch_partials.data_ptr()
+
+        def bind(a):
+            if isinstance(a, tuple) and a and a[0] == 'gnstats':
+                return base + a[1] * slot_bytes
+            if isinstance(a, tuple) and a and a[0] == 'chpart':
+                return cs_base + a[1] * 4
+            return a
         bound = []
         for fn, args, label in self.ops:
-            args = tuple(base + a[1] * slot_bytes if (isinstance(a, tuple) and a and a[0] == 'gnstats') else a
-                         for a in args)
-            bound.append((fn, args, label))
+            bound.append((fn, tuple(bind(a) for a in args), label))
         self.ops = bound
         self.workspace_floats = self.pool.total
         self.buffers = self.pool.all      # owned for the plan's lifetime
@@ -454,7 +492,7 @@ class UNetPlan:
             elif isinstance(layer, torch.nn.Conv2d):
                 assert cur2 is None
                 nxt = self.conv(cur, layer.weight, layer.bias.detach().data_ptr(), layer.weight.shape[0], 3,
-                                label='conv3x3', pad_c_to=cur.C)
+                                label='conv3x3', pad_c_to=cur.C, want_stats=True)
             elif isinstance(layer, M.Downsample):
                 assert cur2 is None
                 nxt = self._downsample(layer, cur)
@@ -484,7 +522,7 @@ class UNetPlan:
         adaptive = rb.use_adaptive_gn
         h1 = self.conv(h0, rb.in_conv.weight, rb.in_conv.bias.detach().data_ptr(), Cout, 3,
                        rowbias=None if adaptive else e_ptr, ld_rowbias=0 if adaptive else self.e_ld,
-                       flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3')
+                       flags=_hip.CONV_IN_UP2X if mode == 'up' else 0, label='conv3x3', want_stats=True)
         self._release(h0)
         if adaptive:   # scale = first half, shift = second half (model.py:201)
             h2 = self.groupnorm(h1, rb.out_norm, scale_ptr=e_ptr, shift_ptr=e_ptr + 4 * Cout, ld_ss=self.e_ld,
@@ -517,7 +555,7 @@ class UNetPlan:
             if mode == 'up':
                 flags |= _hip.CONV_RES_UP2X
         out = self.conv(h2, rb.out_conv.weight, rb.out_conv.bias.detach().data_ptr(), Cout, 3, residual=res,
-                        flags=flags, label='conv3x3')
+                        flags=flags, label='conv3x3', want_stats=True)
         self._release(h2)
         self._release(h1)
         if tmp is not None:

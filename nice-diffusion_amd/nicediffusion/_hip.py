@@ -35,6 +35,9 @@ SIGNATURES = {
                      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_conv3x3_winograd_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
+    'nd_conv3x3_winograd_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                       _i, _i, _i, _i, _i, _vp, _vp],
     'nd_groupnorm_coeffs': [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -60,6 +63,8 @@ _SPECIAL = {
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
+    'nd_conv_winograd_stats_variant': ([], _i),
+    'nd_conv_winograd_stats_floats': ([_i, _i, _i, _i, ctypes.POINTER(_i)], _i64),
     'nd_conv_winograd_variant_info': ([_i] + [ctypes.POINTER(_i)] * 5, _i),
     'nd_conv_winograd_variant_name': ([_i], ctypes.c_char_p),
     'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),

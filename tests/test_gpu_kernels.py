@@ -538,3 +538,46 @@ def test_to_uint8_forms(NI, HW, C):
         v = ((x + 1) * 127.5).clamp(0, 255)
         ref = ((255 - v) if inv else v).to(torch.uint8).reshape(-1)
         assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(3, 64, 192, 16, 16), (4, 32, 96, 8, 8), (2, 96, 40, 12, 20), (1, 32, 64, 64, 64)])
+def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
+    """nd_conv3x3_winograd_stats_nhwc: same output as the plain entry point plus partial per-channel sums / sums of
+    squares of that output; nd_groupnorm_stats_from_partials folds them into what the statistics kernel computes."""
+    import ctypes
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    res = rnd(B, Cout, H, W, seed=4)
+    ref = F.conv2d(x, w, b, padding=1) + res
+    xd, wd, bd, rd = nhwc(x), pack_wino(w), b.to(DEV), nhwc(res)
+    out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+    mbi = ctypes.c_int()
+    nfl = lib().nd_conv_winograd_stats_floats(B, H, W, Cout, ctypes.byref(mbi))
+    assert nfl == B * mbi.value * 8 * Cout
+    ps = torch.full((nfl,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                                     rd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W, Cout, 0,
+                                                     ps.data_ptr(), st()))
+    got = from_nhwc(out, B, H, W, Cout)
+    assert (got - ref).abs().max().item() < 2e-4
+    assert torch.isfinite(ps).all()                      # every partial row is written by every launch
+    c = ps.view(B, mbi.value * 4, 2, Cout).double().sum(1).cpu()      # [B][2][Cout]
+    g64 = got.double()
+    assert (c[:, 0] - g64.sum((2, 3))).abs().max().item() < 1e-3 * max(1.0, g64.sum((2, 3)).abs().max().item())
+    assert ((c[:, 1] - (g64 ** 2).sum((2, 3))).abs() / (g64 ** 2).sum((2, 3))).max().item() < 1e-5
+    if Cout % 32 == 0:
+        rows = mbi.value * 4
+        a = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
+        b2 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_nhwc(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, b2.data_ptr(), B, H * W, 32, st()))
+        assert ((a - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
+        # two-source (concatenated) form vs the statistics kernel on the concatenation [out | out]
+        a2 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, ps.data_ptr(), Cout, rows, a2.data_ptr(), B, 32, st()))
+        b3 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_nhwc(out.data_ptr(), Cout, Cout, out.data_ptr(), Cout, Cout, None, 0, b3.data_ptr(), B, H * W, 32, st()))
+        assert ((a2 - b3).abs() / b3.abs().clamp(min=1.0)).max().item() < 1e-5
+    # ldo must equal N
+    rc = lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                              None, 0, out.data_ptr(), Cout + 4, B, H, W, Cout, 0, ps.data_ptr(), st())
+    assert rc != 0

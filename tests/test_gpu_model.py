@@ -221,6 +221,32 @@ def test_weight_update_invalidates_plan():
     assert (m(x, t, y) - b).abs().max().item() < 1e-6          # weights restored
 
 
+def test_epilogue_statistics_option_matches_default(monkeypatch):
+    """ND_GN_EPILOGUE_STATS=1 (GroupNorm statistics from the conv epilogue instead of a pass over the tensor) gives the
+    same forward as the default plan, on a model large enough for the autotuner to pick the position-split kernel."""
+    cfg = dict(resolution=32, in_channels=3, model_channels=96, out_channels=6, num_res_blocks=1, attention_resolutions=(16,),
+               channel_mult=(1, 2), num_head_channels=32, num_classes=10, use_adaptive_gn=True, resblock_updown=True,
+               split_qkv_first=True)
+    from nicediffusion.model import DiffusionModel
+    torch.manual_seed(0)
+    m = DiffusionModel(**cfg).to(DEV)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.abs().max() == 0:
+                p_.normal_(0, 0.02)
+    x, t, y = torch.randn(16, 3, 32, 32, device=DEV), torch.full((16,), 321, device=DEV), torch.arange(16, device=DEV) % 10
+    a = m(x, t, y).clone()
+    monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '1')
+    m._plans = {}
+    b = m(x, t, y).clone()
+    plan = m._plan(16)
+    used = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_conv3x3_winograd_stats_nhwc')
+    monkeypatch.delenv('ND_GN_EPILOGUE_STATS')
+    m._plans = {}
+    assert torch.isfinite(b).all() and (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+    assert used > 0, 'the option did not engage (the tuner chose other kernels for every conv)'
+
+
 def test_full_size_properties_config2():
     """BASELINE configs[1] shape (64x64 preset, B=64): size-independent properties instead of a CPU oracle run.
     (a) rows are independent: a B=64 forward reproduces the B=2 forward of the same rows;
