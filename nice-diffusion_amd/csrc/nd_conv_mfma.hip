@@ -1267,6 +1267,10 @@ __global__ void __launch_bounds__(1024, 4)
         __builtin_amdgcn_s_barrier();
     }
 
+#if defined(ND_WABL_NOEPI)
+    if (acc[0][0] == 123.456f && acc[1][3] == 1.5f && acc[2][7] == 2.5f) p.out[0] = 1.f;
+    return;
+#endif
     // ---- epilogue: three rounds (one per n tile) through two exchange buffers ex[buf][pos][group][lane][4].
     //      Accumulators are M^T (row = channel, col = tile): register group g4 of a lane = 4 consecutive channels of its
     //      tile.  Reader wave w finishes output pixel (a, b) = (w >> 3, (w >> 2) & 1) of channel group g4 = w & 3:
@@ -1280,6 +1284,18 @@ __global__ void __launch_bounds__(1024, 4)
     const int img = img0 + li;
     const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
     const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
+    // residual rows of the three rounds are fetched now, so that their HBM latency hides behind the LDS exchange
+    f32x4 resv[WNT];
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
+        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
+            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                        : ((size_t)(img * p.H + oy) * p.W + ox);
+            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
+        }
+    }
     __syncthreads();            // last chunk's halo fully consumed
 #pragma unroll
     for (int rr = 0; rr < WNT; ++rr) {
@@ -1320,7 +1336,7 @@ __global__ void __launch_bounds__(1024, 4)
                 if (vec) {
                     if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
                     if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                    yv += resv[rr];           // zeros without a residual
                     if (p.silu_out) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
@@ -1562,6 +1578,17 @@ __global__ void __launch_bounds__(1024, 4)
     const int img = img0 + li;
     const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
     const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
+    f32x4 resv[WNT];           // residual rows, fetched ahead of the LDS exchange (see conv_wino16_kernel)
+#pragma unroll
+    for (int rr = 0; rr < WNT; ++rr) {
+        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
+        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
+            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                        : ((size_t)(img * p.H + oy) * p.W + ox);
+            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < WNT; ++rr) {
         {
@@ -1598,7 +1625,7 @@ __global__ void __launch_bounds__(1024, 4)
                 if (vec) {
                     if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
                     if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                    yv += resv[rr];
                     if (p.silu_out) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
