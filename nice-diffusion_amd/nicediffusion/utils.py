@@ -18,101 +18,91 @@ DIFFUSION_KEYS = ('rescaled_num_steps', 'original_num_steps', 'use_ddim', 'ddim_
                   'sampling_var_type', 'classifier', 'guidance_method', 'guidance_strength', 'loss_type')
 
 
+# Flag tables: (flags, value type | 'flag', default, who must give it, help).  "who": 'always' | 'train' (required when
+# training, optional when sampling) | None (never required).  Names, types and defaults are those of the reference's
+# parsers (utils.py:28-142); the help texts are this build's.
+_SAMPLE_FLAGS = (
+    (('--model_path',), str, None, 'always', 'state-dict file of the model'),
+    (('-c', '--custom'), 'flag', False, None, 'take the architecture / diffusion settings from the flags, not a preset'),
+    (('--batch_size',), int, None, 'always', 'images per batch'),
+    (('--num_samples',), int, None, 'always', 'number of batches (total images = num_samples * batch_size)'),
+    (('--upsample',), 'flag', False, None, '4x Real-ESRGAN super-resolution of the results (needs basicsr)'),
+    (('--wordy', '-w'), 'flag', False, None, 'print progress'),
+    (('--save_path',), str, None, None, 'directory prefix for the JPGs; without it the images are displayed'),
+    (('--labels',), str, '', None, 'class labels, one per batch, separated by "/"; random when omitted'),
+    (('--start_img',), str, None, None, 'image to noise and then denoise (img2img); default is pure noise'),
+    (('--steps_to_do',), int, None, None, 'how many (original-scale) steps of noise to apply to start_img'),
+    (('--seed',), int, None, None, 'RNG seed'),
+    (('--cpu',), 'flag', False, None, 'reference flag; this build has no CPU sampling path and refuses it'),
+)
+_TRAIN_FLAGS = (
+    (('--batch_size',), int, None, 'always', 'images per batch'),
+    (('--lr',), float, None, 'always', 'learning rate'),
+    (('--weight_decay',), float, None, 'always', 'weight decay'),
+    (('--iterations',), int, None, 'always', 'training iterations'),
+    (('--resume_step',), int, 0, None, 'checkpoint step'),
+    (('--wordy', '-w'), 'flag', False, None, 'print progress'),
+    (('--save_every',), int, None, None, 'checkpoint period'),
+    (('--sample_every',), int, None, None, 'sampling period'),
+    (('--ema_rate',), float, 0.9999, None, 'EMA rate'),
+    (('--use_fp16',), 'flag', False, None, 'unused'),
+    (('--grad_accumulation',), int, 1, None, 'optimizer step period'),
+    (('--seed',), int, None, None, 'RNG seed'),
+)
+_MODEL_FLAGS = (
+    (('--resolution',), int, None, 'train', 'image height = width'),
+    (('--model_channels',), int, None, 'train', 'base channel count'),
+    (('--channel_mult',), str, None, 'train', 'per-level channel multipliers, "/"-separated'),
+    (('--num_res_blocks',), int, None, 'train', 'residual blocks per level'),
+    (('--attention_resolutions',), str, None, 'train', 'resolutions that get attention, "/"-separated'),
+    (('--num_classes',), int, None, None, 'class count of a conditional model'),
+    (('--dropout',), float, 0.0, 'train', 'dropout probability'),
+    (('--in_channels',), int, 3, None, 'image channels'),
+    (('--num_heads',), int, 4, None, 'attention heads'),
+    (('--num_head_channels',), int, None, None, 'channels per attention head (overrides num_heads)'),
+    (('--split_qkv_first',), 'flag', False, None, 'qkv channel order: q|k|v blocks first, heads inside'),
+    (('--resblock_updown',), 'flag', False, None, 'resample inside residual blocks'),
+    (('--use_adaptive_gn',), 'flag', False, None, 'adaptive GroupNorm (scale/shift from the timestep embedding)'),
+)
+_DIFFUSION_FLAGS = (
+    (('--rescaled_num_steps',), int, None, 'train', 'number of sampling steps'),
+    (('--beta_schedule',), str, None, 'train', "'linear', 'cosine' or 'constant'"),
+    (('--sampling_var_type',), str, None, 'train', "'small', 'large', 'learned' or 'learned_interpolation'"),
+    (('--use_ddim',), 'flag', False, None, 'DDIM sampler'),
+    (('--ddim_eta',), float, 0.0, None, 'DDIM eta'),
+    (('--original_num_steps',), int, 1000, None, 'steps the model was trained with'),
+    (('--loss_type',), str, 'hybrid', 'train', "'simple', 'KL', 'KL_rescaled' or 'hybrid'"),
+    (('--guidance_method',), str, None, None, "'classifier' or 'classifier_free'"),
+    (('--guidance_strength',), float, None, None, 'guidance weight'),
+    (('--classifier_path',), str, None, None, 'classifier state dict (classifier guidance is not implemented)'),
+)
+
+
+def _add_flags(group, table, training):
+    for flags, kind, default, who, text in table:
+        needed = who == 'always' or (who == 'train' and training)
+        if kind == 'flag':
+            group.add_argument(*flags, action='store_true', default=default, required=False, help=text)
+        else:
+            group.add_argument(*flags, type=kind, default=default, required=needed,
+                               metavar='(required)' if needed else '(optional)', help=text)
+
+
 def make_argparser(prog):
     """Argument parser for ``'diff_sample'`` (and, for surface compatibility, ``'diff_train'``)."""
-    if prog == 'diff_sample':
-        sampling, about = True, 'Draw images from a diffusion model on an AMD Instinct GPU.'
-    elif prog == 'diff_train':
-        sampling, about = False, 'Train a diffusion model (not part of this build; parser kept for compatibility).'
-    else:
+    if prog not in ('diff_sample', 'diff_train'):
         raise NotImplementedError(prog)
-    req, opt = '(required)', '(optional)'
-    p = argparse.ArgumentParser(prog=prog, description=about)
-
-    if sampling:
-        g = p.add_argument_group('sampling arguments', 'what to sample and where to put it')
-        g.add_argument('--model_path', type=str, required=True, metavar=req, help='state-dict file of the model')
-        g.add_argument('-c', '--custom', required=False, action='store_true', default=False,
-                       help='take the architecture / diffusion settings from the flags instead of a preset')
-        g.add_argument('--batch_size', type=int, required=True, metavar=req, help='images per batch')
-        g.add_argument('--num_samples', type=int, required=True, metavar=req,
-                       help='number of batches (total images = num_samples * batch_size)')
-        g.add_argument('--upsample', required=False, default=False, action='store_true',
-                       help='4x Real-ESRGAN super-resolution of the results (needs basicsr)')
-        g.add_argument('--wordy', '-w', dest='wordy', required=False, default=False, action='store_true',
-                       help='print progress')
-        g.add_argument('--save_path', type=str, required=False, metavar=opt, default=None,
-                       help='directory prefix for the JPGs; without it the images are displayed')
-        g.add_argument('--labels', type=str, required=False, metavar=opt, default='',
-                       help='class labels, one per batch, separated by "/"; random when omitted')
-        g.add_argument('--start_img', type=str, required=False, metavar=opt, default=None,
-                       help='image to noise and then denoise (img2img); default is pure noise')
-        g.add_argument('--steps_to_do', type=int, required=False, metavar=opt, default=None,
-                       help='how many (original-scale) steps of noise to apply to start_img')
-        g.add_argument('--seed', type=int, required=False, metavar=opt, default=None, help='RNG seed')
-        g.add_argument('--cpu', required=False, default=False, action='store_true',
-                       help='reference flag; this build has no CPU sampling path and refuses it')
+    training = prog == 'diff_train'
+    p = argparse.ArgumentParser(prog=prog, description=(
+        'Train a diffusion model (not part of this build; parser kept for compatibility).' if training
+        else 'Draw images from a diffusion model on an AMD Instinct GPU.'))
+    if training:
+        _add_flags(p.add_argument_group('training arguments', 'training loop settings'), _TRAIN_FLAGS, True)
     else:
-        g = p.add_argument_group('training arguments', 'training loop settings')
-        g.add_argument('--batch_size', type=int, required=True, metavar=req, help='images per batch')
-        g.add_argument('--lr', type=float, required=True, metavar=req, help='learning rate')
-        g.add_argument('--weight_decay', type=float, required=True, metavar=req, help='weight decay')
-        g.add_argument('--iterations', type=int, required=True, metavar=req, help='training iterations')
-        g.add_argument('--resume_step', type=int, required=False, metavar=opt, default=0, help='checkpoint step')
-        g.add_argument('--wordy', '-w', dest='wordy', required=False, default=False, action='store_true',
-                       help='print progress')
-        g.add_argument('--save_every', type=int, required=False, metavar=opt, default=None, help='checkpoint period')
-        g.add_argument('--sample_every', type=int, required=False, metavar=opt, default=None, help='sampling period')
-        g.add_argument('--ema_rate', type=float, required=False, metavar=opt, default=0.9999, help='EMA rate')
-        g.add_argument('--use_fp16', required=False, default=False, action='store_true', help='unused')
-        g.add_argument('--grad_accumulation', type=int, required=False, metavar=opt, default=1,
-                       help='optimizer step period')
-        g.add_argument('--seed', type=int, required=False, metavar=opt, default=None, help='RNG seed')
-
-    need = not sampling
-    mv = req if need else opt
-    m = p.add_argument_group('model arguments', 'UNet architecture (only read with --custom when sampling)')
-    m.add_argument('--resolution', type=int, required=need, metavar=mv, default=None, help='image height = width')
-    m.add_argument('--model_channels', type=int, required=need, metavar=mv, default=None, help='base channel count')
-    m.add_argument('--channel_mult', type=str, required=need, metavar=mv, default=None,
-                   help='per-level channel multipliers, "/"-separated')
-    m.add_argument('--num_res_blocks', type=int, required=need, metavar=mv, default=None,
-                   help='residual blocks per level')
-    m.add_argument('--attention_resolutions', type=str, required=need, metavar=mv, default=None,
-                   help='resolutions that get attention, "/"-separated')
-    m.add_argument('--num_classes', type=int, required=False, default=None, metavar=opt,
-                   help='class count of a conditional model')
-    m.add_argument('--dropout', type=float, required=need, default=0.0, metavar=mv, help='dropout probability')
-    m.add_argument('--in_channels', type=int, required=False, default=3, metavar=opt, help='image channels')
-    m.add_argument('--num_heads', type=int, required=False, default=4, metavar=opt, help='attention heads')
-    m.add_argument('--num_head_channels', type=int, required=False, default=None, metavar=opt,
-                   help='channels per attention head (overrides num_heads)')
-    m.add_argument('--split_qkv_first', required=False, default=False, action='store_true',
-                   help='qkv channel order: q|k|v blocks first, heads inside')
-    m.add_argument('--resblock_updown', required=False, default=False, action='store_true',
-                   help='resample inside residual blocks')
-    m.add_argument('--use_adaptive_gn', required=False, default=False, action='store_true',
-                   help='adaptive GroupNorm (scale/shift from the timestep embedding)')
-
-    d = p.add_argument_group('diffusion arguments', 'noise schedule and sampler')
-    d.add_argument('--rescaled_num_steps', type=int, required=need, metavar=mv, default=None,
-                   help='number of sampling steps')
-    d.add_argument('--beta_schedule', type=str, required=need, metavar=mv, default=None,
-                   help="'linear', 'cosine' or 'constant'")
-    d.add_argument('--sampling_var_type', type=str, required=need, metavar=mv, default=None,
-                   help="'small', 'large', 'learned' or 'learned_interpolation'")
-    d.add_argument('--use_ddim', required=False, default=False, action='store_true', help='DDIM sampler')
-    d.add_argument('--ddim_eta', type=float, required=False, default=0.0, metavar=opt, help='DDIM eta')
-    d.add_argument('--original_num_steps', type=int, required=False, default=1000, metavar=opt,
-                   help='steps the model was trained with')
-    d.add_argument('--loss_type', type=str, required=need, default='hybrid', metavar=opt if sampling else req,
-                   help="'simple', 'KL', 'KL_rescaled' or 'hybrid'")
-    d.add_argument('--guidance_method', type=str, required=False, default=None, metavar=opt,
-                   help="'classifier' or 'classifier_free'")
-    d.add_argument('--guidance_strength', type=float, required=False, default=None, metavar=opt,
-                   help='guidance weight')
-    d.add_argument('--classifier_path', metavar=opt, type=str, required=False, default=None,
-                   help='classifier state dict (classifier guidance is not implemented)')
+        _add_flags(p.add_argument_group('sampling arguments', 'what to sample and where to put it'), _SAMPLE_FLAGS, False)
+    _add_flags(p.add_argument_group('model arguments', 'UNet architecture (only read with --custom when sampling)'),
+               _MODEL_FLAGS, training)
+    _add_flags(p.add_argument_group('diffusion arguments', 'noise schedule and sampler'), _DIFFUSION_FLAGS, training)
     return p
 
 
