@@ -1230,7 +1230,7 @@ __global__ void __launch_bounds__(1024, 4)
 #endif
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                // (no sched_barrier here: letting the compiler interleave the loads with the previous MFMAs measures 1-2 % faster)
                 f32x4 v;
                 {
                     int kx = st << 3;
