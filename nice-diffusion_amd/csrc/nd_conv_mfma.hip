@@ -1263,8 +1263,10 @@ __global__ void __launch_bounds__(1024, 4)
                 }
             }
         }
+#if !defined(ND_WABL_NOBARRIER)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
     }
 
 #if defined(ND_WABL_NOEPI)
