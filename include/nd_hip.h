@@ -181,17 +181,19 @@ int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld,
  *   [0,C) = epsilon, [C,2C) = variance head.  eps_uncond != NULL applies classifier-free guidance
  *   eps = (1+w)*eps - w*eps_uncond (diffusion.py:284,347).
  * noise: NHWC like x, indexed noise + t*noise_step_stride (floats) | NULL.  If NULL and noise is needed
- *   (eta != 0 / DDPM) it is drawn in-kernel from Philox4x32-10 keyed by (seed, t, element).
+ *   (eta != 0 / DDPM) it is drawn in-kernel from Philox4x32-10 keyed by (seed, t, first_elem + element), element =
+ *   (b*HW + p)*C + c: a rank that denoises rows [r0, r1) of a larger batch passes first_elem = r0*HW*C and draws
+ *   exactly the numbers a single process would have drawn for those rows.
  */
 int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step, int64_t* t_out, int B, nd_stream_t stream);
 int nd_step_advance(int32_t* step, int delta, nd_stream_t stream);
 int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, float eta,
-                 const float* noise, int64_t noise_step_stride, uint64_t seed,
+                 const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem,
                  int B, int HW, int C, nd_stream_t stream);
 int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, int var_kind,
-                 const float* noise, int64_t noise_step_stride, uint64_t seed,
+                 const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem,
                  int B, int HW, int C, nd_stream_t stream);
 /* forward diffusion q(x_t | x_0) = sqrt(abar_t) x0 + sqrt(1-abar_t) noise (diffusion.py:232-240) */
 int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,

@@ -63,6 +63,7 @@ struct StepArgs {
     const float* noise;
     int64_t noise_stride;
     uint64_t seed;
+    uint64_t idx0;     // index of this call's first element in the unpadded [B][HW][C] order of the WHOLE (unsharded) batch
     int ldx, ld_eps, HW, C;
     float w, eta;
     int var_kind;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) step_elem_kernel(const StepArgs a) {
         const float xt = a.x[px];
         const float e = mix_eps(a, a.eps[pe + c], a.eps_u ? a.eps_u[pe + c] : 0.f);
         float nz = 0.f;
-        if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, (uint64_t)it);
+        if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, a.idx0 + (uint64_t)it);
         a.x_out[px] = DDIM ? ddim_elem(k, xt, e, nz) : ddpm_elem(a, cf, t, xt, e, learned ? a.eps[pe + a.C + c] : 0.f, nz);
     }
 }
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) step_pixel_kernel(const StepArgs a) {
                 nz = *reinterpret_cast<const f32x4*>(a.noise + (size_t)t * a.noise_stride + pix * 4);
             } else {
                 // the C elements of a pixel span at most two Philox pairs
-                const uint64_t it0 = (uint64_t)pix * C, p0 = it0 >> 1;
+                const uint64_t it0 = a.idx0 + (uint64_t)pix * C, p0 = it0 >> 1;
                 float g[4];
                 philox_normal_pair(a.seed, t, p0, g[0], g[1]);
                 g[2] = g[3] = 0.f;
@@ -202,7 +203,8 @@ __global__ void step_advance_kernel(int32_t* step, int delta) {
 
 static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, int ldx, const float* eps,
                        const float* eps_u, int ld_eps, float w, const float* coef, const int32_t* step, float eta,
-                       int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, int B, int HW, int C,
+                       int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, uint64_t first_elem, int B, int HW,
+                       int C,
                        nd_stream_t stream) {
     ND_REQUIRE(x && x_out && eps && coef && step, fn, "null pointer");
     ND_REQUIRE(B > 0 && HW > 0 && C > 0 && ldx >= C, fn, "bad shape");
@@ -211,7 +213,7 @@ static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, 
     ND_REQUIRE(var_kind >= 0 && var_kind <= 2, fn, "bad var_kind");
     StepArgs a;
     a.x = x; a.x_out = x_out; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
-    a.noise_stride = noise_stride; a.seed = seed; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
+    a.noise_stride = noise_stride; a.seed = seed; a.idx0 = first_elem; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
     a.eta = eta; a.var_kind = var_kind; a.total = (long)B * HW * C;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool image_form = ldx == 4 && (ld_eps == 4 || ld_eps == 8) && C <= 4 && aligned16(x) && aligned16(x_out) &&
@@ -247,18 +249,18 @@ using namespace nd;
 
 extern "C" int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, float eta,
-                            const float* noise, int64_t noise_step_stride, uint64_t seed, int B, int HW, int C,
-                            nd_stream_t stream) {
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem, int B,
+                            int HW, int C, nd_stream_t stream) {
     return launch_step(true, "nd_ddim_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, eta,
-                       ND_VAR_FIXED, noise, noise_step_stride, seed, B, HW, C, stream);
+                       ND_VAR_FIXED, noise, noise_step_stride, seed, first_elem, B, HW, C, stream);
 }
 
 extern "C" int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, int var_kind,
-                            const float* noise, int64_t noise_step_stride, uint64_t seed, int B, int HW, int C,
-                            nd_stream_t stream) {
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem, int B,
+                            int HW, int C, nd_stream_t stream) {
     return launch_step(false, "nd_ddpm_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, 0.f,
-                       var_kind, noise, noise_step_stride, seed, B, HW, C, stream);
+                       var_kind, noise, noise_step_stride, seed, first_elem, B, HW, C, stream);
 }
 
 extern "C" int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,

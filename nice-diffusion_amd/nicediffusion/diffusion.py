@@ -126,6 +126,7 @@ class Diffusion:
 
         self.use_graph = True          # capture the step body as a hipGraph
         self.seed = None               # Philox seed for in-kernel noise; None -> drawn from torch's CPU generator
+        self.first_row = 0             # row of the global batch this process's row 0 is (set by denoise_sharded)
         self._loops = {}
 
     # ---------------------------------------------------------------------------------------------- device tables
@@ -262,6 +263,7 @@ class Diffusion:
             _hip.check(lib.nd_nchw_to_nhwc(nz.data_ptr(), nb.data_ptr(), S * B, C, HW, plan.Cin_p, stream),
                        'nd_nchw_to_nhwc')
             noise_ptr, noise_stride = nb.data_ptr(), B * HW * plan.Cin_p
+        first_elem = int(self.first_row) * HW * C      # Philox counters of a shard continue the global batch's
         seed = self.seed
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -292,10 +294,10 @@ class Diffusion:
             plan.run()
             if self.use_ddim:
                 rc = lib.nd_ddim_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
-                                      st['step'].data_ptr(), eta, noise_ptr, noise_stride, seed, B, HW, C, s)
+                                      st['step'].data_ptr(), eta, noise_ptr, noise_stride, seed, first_elem, B, HW, C, s)
             else:
                 rc = lib.nd_ddpm_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
-                                      st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, seed, B, HW, C, s)
+                                      st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, seed, first_elem, B, HW, C, s)
             _hip.check(rc, 'sampler step')
             if cfg:
                 plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
@@ -314,7 +316,7 @@ class Diffusion:
             bar = tqdm.tqdm(total=steps_to_do)
         use_graph = self.use_graph and trace is None and steps_to_do > 1
         gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, seed if need_noise and noise_ptr is None
-                else 0)
+                else 0, first_elem)
         done = 0
         if use_graph:
             if st['graph'] is None or st['graph_key'] != gkey:
@@ -362,7 +364,16 @@ class Diffusion:
         if kwargs is not None:
             lk = {k: (v[sl] if v is not None else None) for k, v in kwargs.items()}
         ln = None if noise is None else noise[:, sl]
-        local = self.denoise(x=x[sl], kwargs=lk, batch_size=sl.stop - sl.start, noise=ln, **kw)
+        # in-kernel noise: every rank must use the same Philox seed (drawn here from torch's CPU generator, which the
+        # ranks seed identically to build the same global x) and continue the global element count at its first row
+        saved = (getattr(self, 'seed', None), getattr(self, 'first_row', 0))
+        if saved[0] is None:
+            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.first_row = sl.start
+        try:
+            local = self.denoise(x=x[sl], kwargs=lk, batch_size=sl.stop - sl.start, noise=ln, **kw)
+        finally:
+            self.seed, self.first_row = saved
         return all_gather_rows(local, x.shape[0], rank, world)
 
     def loss(self, *a, **k):
