@@ -167,6 +167,11 @@ int nd_attention_nhwc(const float* qkv, int ld_qkv, float* out, int ld_out, int 
 
 /* ---- K8: standalone 2x resampling (Upsample/Downsample without conv, model.py:77,111; x path of :193) ------- */
 int nd_upsample2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
+/* Space-to-depth by 2 (even H, W): out[img][y][x][(p*2+q)*C + c] = x[img][2y+p][2x+q][c], out is [NI][H/2][W/2][4C].
+ * The stride-2 3x3 Downsample convolution (model.py:103-108) is then the stride-1 3x3 convolution of `out` with the
+ * weights w'[n][(p,q,c)][u][v] = w[n][c][dy][dx], (dy -> p,u): 0 -> (1,0), 1 -> (0,1), 2 -> (1,1) (same for dx -> q,v), zero
+ * elsewhere -- i.e. it runs on nd_conv_nhwc / nd_conv3x3_winograd_nhwc. */
+int nd_space_to_depth2_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
 int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
 
 /* ---- layout at the API edge: NCHW [NI][C][HW] <-> NHWC [NI][HW][ld] (pad channels written as 0) ------------- */

@@ -54,6 +54,26 @@ __global__ void upsample2x_kernel(const float* x, int ldx, float* out, int ldo, 
     }
 }
 
+// space-to-depth by 2: out[img][y][x][(p*2+q)*C + c] = x[img][2y+p][2x+q][c].  A stride-2 3x3 convolution (Downsample,
+// model.py:103-108) is a stride-1 3x3 convolution of this tensor with rearranged (and partly zero) weights, so it runs on
+// the MFMA / Winograd kernels instead of a one-thread-per-output loop.
+__global__ void space_to_depth2_kernel(const float* x, int ldx, float* out, int ldo, int H, int W, int CQ, long total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int qd = (int)(it % CQ);
+        long r = it / CQ;
+        const int pq = (int)(r & 3);
+        r >>= 2;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long img = r / Ho;
+        const size_t src = ((size_t)(img * H + 2 * oy + (pq >> 1)) * W + 2 * ox + (pq & 1)) * ldx + qd * 4;
+        const size_t dst = ((size_t)(img * Ho + oy) * Wo + ox) * ldo + (size_t)pq * CQ * 4 + qd * 4;
+        *reinterpret_cast<f32x4*>(out + dst) = *reinterpret_cast<const f32x4*>(x + src);
+    }
+}
+
 __global__ void avgpool2x_kernel(const float* x, int ldx, float* out, int ldo, int H, int W, int CQ, long total) {
     const int Ho = H >> 1, Wo = W >> 1;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -224,6 +244,19 @@ extern "C" int nd_upsample2x_nhwc(const float* x, int ldx, float* out, int ldo, 
     const long total = (long)NI * 4 * H * W * (C >> 2);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out,
                        ldo, H, W, C >> 2, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_space_to_depth2_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C,
+                                      nd_stream_t stream) {
+    const char* fn = "nd_space_to_depth2_nhwc";
+    ND_REQUIRE(x && out && NI > 0 && H > 1 && W > 1 && C > 0, fn, "bad arguments");
+    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "H and W must be even");
+    ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= C && ldo >= 4 * C && aligned16(x) && aligned16(out),
+               fn, "alignment / strides");
+    const long total = (long)NI * (H >> 1) * (W >> 1) * 4 * (C >> 2);
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out, ldo,
+                       H, W, C >> 2, total);
     return check_launch(fn);
 }
 

@@ -595,6 +595,25 @@ class UNetPlan:
             N = layer.conv.weight.shape[0]
             w = layer.conv.weight.detach()
             assert w.is_contiguous()
+            if x.H % 2 == 0 and x.W % 2 == 0:
+                # stride 2 = stride 1 on the space-to-depth tensor with rearranged weights (tap index 0 of the new kernel is
+                # offset -1): (dy -> parity p, tap u): 0 -> (1, 0), 1 -> (0, 1), 2 -> (1, 1); the rest is zero.  4x the
+                # MACs of the strided form, on the MFMA / Winograd kernels instead of a scalar loop (79 ms -> < 1 ms for
+                # 64x64x192 at B=64).
+                C = x.C
+                w2 = torch.zeros((N, 4, C, 3, 3), dtype=w.dtype, device=w.device)
+                mp = ((1, 0), (0, 1), (1, 1))
+                for dy in range(3):
+                    for dx in range(3):
+                        (p_, u), (q_, v) = mp[dy], mp[dx]
+                        w2[:, p_ * 2 + q_, :, u, v] = w[:, :, dy, dx]
+                w2 = w2.reshape(N, 4 * C, 3, 3).contiguous()
+                self.keep.append(w2)
+                s2d = self._new(NI, x.H // 2, x.W // 2, 4 * C)
+                self._emit(self.lib.nd_space_to_depth2_nhwc, [x.ptr, x.ld, s2d.ptr, s2d.ld, NI, x.H, x.W, C], 'space_to_depth')
+                out = self.conv(s2d, w2, layer.conv.bias.detach().data_ptr(), N, 3, label='conv_s2')
+                self._release(s2d)
+                return out
             Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
             out = self._new(NI, Ho, Wo, N)
             self._emit(self.lib.nd_conv_direct_nhwc, [x.ptr, x.C, x.ld, w.data_ptr(),

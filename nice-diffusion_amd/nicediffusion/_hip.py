@@ -48,6 +48,7 @@ SIGNATURES = {
     'nd_attention_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     'nd_upsample2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_avgpool2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_space_to_depth2_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_nchw_to_nhwc': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_nhwc_to_nchw': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_fill_timestep': [_vp, _vp, _vp, _i, _vp],

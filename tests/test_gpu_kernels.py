@@ -581,3 +581,28 @@ def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
     rc = lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                               None, 0, out.data_ptr(), Cout + 4, B, H, W, Cout, 0, ps.data_ptr(), st())
     assert rc != 0
+
+
+@pytest.mark.parametrize('B,C,N,H,W', [(2, 32, 48, 16, 16), (3, 64, 64, 8, 12)])
+def test_stride2_conv_via_space_to_depth(B, C, N, H, W):
+    """Downsample's stride-2 3x3 conv (model.py:103-108) = stride-1 3x3 conv of the space-to-depth tensor with the
+    rearranged weights documented in nd_hip.h (what nicediffusion/_engine.py:_downsample emits)."""
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 3, 3, seed=2, scale=0.05), rnd(N, seed=3)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    xd = nhwc(x)
+    s2d = torch.full((B * (H // 2) * (W // 2) * 4 * C,), float('nan'), device=DEV)
+    _hip.check(lib().nd_space_to_depth2_nhwc(xd.data_ptr(), C, s2d.data_ptr(), 4 * C, B, H, W, C, st()))
+    got = s2d.view(B, H // 2, W // 2, 2, 2, C).cpu()
+    assert torch.equal(got, x.permute(0, 2, 3, 1).reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5))
+    w2 = torch.zeros(N, 4, C, 3, 3)
+    mp = ((1, 0), (0, 1), (1, 1))
+    for dy in range(3):
+        for dx in range(3):
+            (p_, u), (q_, v) = mp[dy], mp[dx]
+            w2[:, p_ * 2 + q_, :, u, v] = w[:, :, dy, dx]
+    wd, bd = pack_w(w2.reshape(N, 4 * C, 3, 3)), b.to(DEV)
+    out = torch.full((B * (H // 2) * (W // 2) * N,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv_nhwc(s2d.data_ptr(), 4 * C, 4 * C, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                  out.data_ptr(), N, B, H // 2, W // 2, N, 3, 0, -1, None, None, 0, st()))
+    assert (from_nhwc(out, B, H // 2, W // 2, N) - ref).abs().max().item() < 2e-4
+    assert lib().nd_space_to_depth2_nhwc(xd.data_ptr(), C, s2d.data_ptr(), 4 * C, B, H - 1, W, C, st()) != 0
