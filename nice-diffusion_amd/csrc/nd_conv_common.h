@@ -1,0 +1,97 @@
+// Shared by the convolution translation units: launch arguments, block -> tile order, tile planning helpers.
+#pragma once
+#include "nd_common.h"
+#include <stdlib.h>
+
+#ifndef ND_SETPRIO
+#define ND_SETPRIO 0
+#endif
+#if ND_SETPRIO
+#define ND_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ND_PRIO(x)
+#endif
+
+namespace nd {
+
+struct ConvArgs {
+    const float* x0;
+    const float* x1;
+    const float* w;      // packed fragments
+    const float* bias;
+    const float* rowbias;
+    const float* res;
+    float* out;
+    int C0, C1, ldx0, ldx1;
+    int NI, H, W;      // output (= virtual input) size
+    int Hs, Ws;        // stored input size (H >> up)
+    int up;            // input read through nearest-2x upsampling
+    int res_up;        // residual read through nearest-2x upsampling
+    int N, ldo, ldr, ld_rowbias;
+    int NT32;          // ceil(N / 32)
+    int NC32;          // ceil(Cin / 32)
+    int thl, twl, nibl;   // log2 of tile height / width / images per block
+    int tiles_x, tiles_y, mt, nt;
+    int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
+    int nhi;           // Winograd: halo items per thread actually needed for this tiling
+    const float* zero; // 16 bytes of zeros in device memory (LDS-DMA source for padding)
+    float* chstats;    // optional partial output statistics [NI][mbi][4][2][N] (see conv_wino16_kernel's epilogue)
+    int mbi;           // m blocks per image (1 when a block holds whole images)
+    int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
+    int silu_out;
+    // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
+    const float* gnA;
+    const float* gnB;
+    int ld_gn, gn_silu, gn_hw;    // gn_hw > 0: flat pixel list, image = pixel / gn_hw
+};
+
+// Block -> tile order.  The n tiles are taken in groups of `ngroup`; inside a group the walk is m-major with n fastest,
+// so the blocks resident at one time on an XCD (consecutive ids) cover a few m tiles x ngroup n tiles: each input tile is
+// pulled from HBM once per GROUP and shared through L2 by the ngroup blocks that use it, each weight slab once per m
+// row.  ngroup = 1 is the n-major order (weights stay put, inputs re-read nt times), ngroup = nt the m-major one.
+__device__ inline void tile_of(int idp, int mt, int nt, int ngroup, int& mblk, int& nblk) {
+    const int per_group = ngroup * mt;
+    const int g = idp / per_group;
+    const int rem = idp - g * per_group;
+    const int left = nt - g * ngroup;
+    const int gn = left < ngroup ? left : ngroup;
+    mblk = rem / gn;
+    nblk = g * ngroup + (rem - mblk * gn);
+}
+
+static inline int env_ngroup() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("ND_NGROUP");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
+// n tiles per group.  Measured with FETCH_SIZE on B=64 layers (tools/ngroup_fetch.sh): all n tiles when the whole
+// weight tensor sits comfortably in an XCD's 4 MiB L2 (input then crosses HBM once: 333 MB instead of 1245 MB per
+// launch for 64x64x192->192), otherwise 4 (786 vs 1327 MB for 32x32x384->384; m-major thrashes the weights: 1883 MB).
+// Run time is within 1 % across orders -- the point is not to burn HBM bandwidth and power on re-reads.
+static inline int pick_ngroup(int nt, size_t bytes_per_ntile) {
+    int g = env_ngroup();
+    if (g <= 0) g = ((size_t)nt * bytes_per_ntile <= ((size_t)3 << 20)) ? nt : 4;
+    return g > nt ? nt : g;
+}
+
+__host__ __device__ inline int nc32_padded(int C) {
+    const int c = (C + 31) / 32;
+    return (c + 1) & ~1;      // even number of 32-channel chunks (the 1x1 kernel walks two per barrier)
+}
+
+struct TilePlan {
+    int thl, twl, nibl, tiles_x, tiles_y, groups, hp;
+    long padded;   // padded pixel count
+};
+
+static inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace nd

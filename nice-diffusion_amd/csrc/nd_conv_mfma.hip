@@ -23,88 +23,9 @@
 //               behind the MFMAs of that tap.
 //   grid        one block per (m tile, n tile), remapped so that each XCD gets a contiguous, n-major range of
 //               tiles (blocks resident on one XCD stream the same weight fragments through that XCD's L2).
-#include "nd_common.h"
-#include <stdlib.h>
-
-#ifndef ND_SETPRIO
-#define ND_SETPRIO 0
-#endif
-#if ND_SETPRIO
-#define ND_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define ND_PRIO(x)
-#endif
+#include "nd_conv_common.h"
 
 namespace nd {
-
-struct ConvArgs {
-    const float* x0;
-    const float* x1;
-    const float* w;      // packed fragments
-    const float* bias;
-    const float* rowbias;
-    const float* res;
-    float* out;
-    int C0, C1, ldx0, ldx1;
-    int NI, H, W;      // output (= virtual input) size
-    int Hs, Ws;        // stored input size (H >> up)
-    int up;            // input read through nearest-2x upsampling
-    int res_up;        // residual read through nearest-2x upsampling
-    int N, ldo, ldr, ld_rowbias;
-    int NT32;          // ceil(N / 32)
-    int NC32;          // ceil(Cin / 32)
-    int thl, twl, nibl;   // log2 of tile height / width / images per block
-    int tiles_x, tiles_y, mt, nt;
-    int ngroup;        // n tiles per group of the block -> tile order (see tile_of)
-    int nhi;           // Winograd: halo items per thread actually needed for this tiling
-    const float* zero; // 16 bytes of zeros in device memory (LDS-DMA source for padding)
-    float* chstats;    // optional partial output statistics [NI][mbi][4][2][N] (see conv_wino16_kernel's epilogue)
-    int mbi;           // m blocks per image (1 when a block holds whole images)
-    int vec_ok;        // Winograd epilogue: 16-byte stores / loads are legal (strides and pointers aligned)
-    int silu_out;
-    // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels
-    const float* gnA;
-    const float* gnB;
-    int ld_gn, gn_silu, gn_hw;    // gn_hw > 0: flat pixel list, image = pixel / gn_hw
-};
-
-// Block -> tile order.  The n tiles are taken in groups of `ngroup`; inside a group the walk is m-major with n fastest,
-// so the blocks resident at one time on an XCD (consecutive ids) cover a few m tiles x ngroup n tiles: each input tile is
-// pulled from HBM once per GROUP and shared through L2 by the ngroup blocks that use it, each weight slab once per m
-// row.  ngroup = 1 is the n-major order (weights stay put, inputs re-read nt times), ngroup = nt the m-major one.
-__device__ inline void tile_of(int idp, int mt, int nt, int ngroup, int& mblk, int& nblk) {
-    const int per_group = ngroup * mt;
-    const int g = idp / per_group;
-    const int rem = idp - g * per_group;
-    const int left = nt - g * ngroup;
-    const int gn = left < ngroup ? left : ngroup;
-    mblk = rem / gn;
-    nblk = g * ngroup + (rem - mblk * gn);
-}
-
-static int env_ngroup() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("ND_NGROUP");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
-}
-
-// n tiles per group.  Measured with FETCH_SIZE on B=64 layers (tools/ngroup_fetch.sh): all n tiles when the whole
-// weight tensor sits comfortably in an XCD's 4 MiB L2 (input then crosses HBM once: 333 MB instead of 1245 MB per
-// launch for 64x64x192->192), otherwise 4 (786 vs 1327 MB for 32x32x384->384; m-major thrashes the weights: 1883 MB).
-// Run time is within 1 % across orders -- the point is not to burn HBM bandwidth and power on re-reads.
-static int pick_ngroup(int nt, size_t bytes_per_ntile) {
-    int g = env_ngroup();
-    if (g <= 0) g = ((size_t)nt * bytes_per_ntile <= ((size_t)3 << 20)) ? nt : 4;
-    return g > nt ? nt : g;
-}
-
-__host__ __device__ inline int nc32_padded(int C) {
-    const int c = (C + 31) / 32;
-    return (c + 1) & ~1;      // even number of 32-channel chunks (the 1x1 kernel walks two per barrier)
-}
 
 template <int WM, int WN, int TM, int TN, int TAPS, int OCC>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
@@ -688,998 +609,6 @@ __global__ void pack_conv_weight_kernel(const float* w, float* out, int N, int C
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) form of the 3x3 convolution: 16 multiplies per 2x2 output block instead of 36, i.e. 2.25x
-// fewer MFMAs than the direct form above for the same result (Y = A^T [ (G g G^T) .* (B^T d B) ] A, all fp32;
-// the transform matrices only hold 0, +-1, +-1/2, so the rounding error stays within a few ulp of the direct sum).
-//   * the weights are transformed once at pack time (U = G g G^T) and stored in fragment order
-//     [c32][n tile][kc][position 16][lane][4];
-//   * the input transform V = B^T d B is computed on the fly from the SAME LDS halo tile the direct kernel stages
-//     (no extra HBM pass), the output transform A^T M A in the epilogue: only the final NHWC result is written.
-// The 16 transform positions are split over 4 waves by row xi of the 4x4 transform (wave
-// w: xi = w & 3, n tile = w >> 2; 8 waves = 2 waves per SIMD), each wave owning TMW x 32 tiles x 32 channels x the 4
-// positions (xi, nu = 0..3) = TMW*64 accumulator registers.  Per B fragment it issues TMW*4 MFMAs (twice the reuse of
-// the form above at TMW = 2), reads only the two patch rows its xi needs, and two waves per SIMD hide each other's
-// LDS / L2 latency.  The output transform needs all four xi: Y[a][b] = sum_xi At[a][xi] * r_xi[b] with
-// r_xi[b] = sum_nu At[b][nu] M[xi][nu] computed in registers and exchanged once through LDS in the epilogue.
-// NSUB = 32-channel sub-chunks per LDS chunk (2 halves the barrier count; needs the smaller TMW = 1 halo);
-// APF = read the raw patch entries of the next k-step ahead of this step's MFMAs (TMW = 1 has the registers for it).
-template <int TMW, int NSUB, bool APF, int WNT>
-__global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
-    conv_wino_kernel(const ConvArgs p) {
-    constexpr int NT = 256 * WNT;                   // 4 waves (one per transform row xi) per 32-channel n tile
-    constexpr int BN = 32 * WNT;
-    constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
-    constexpr int FRAGS = 64;
-    // halo float4 items per thread per chunk.  The host only picks tilings with at most HPMAX halo pixels (180 for a
-    // 8x16 tile, 200 for two 8x8 images, 324 for 16x16), so a thread owns at most MAXHI of them; how many are really
-    // needed (p.nhi = ceil(HP * SPR / NT), uniform) is decided per launch, and they are fetched in two batches of HB
-    constexpr int HPMAX = (TMW == 2) ? 384 : ((WNT == 3) ? 208 : 192);
-    constexpr int MAXHI = (HPMAX * SPR + NT - 1) / NT;
-    constexpr int HB = (MAXHI + 1) / 2;
-    static_assert(MAXHI >= 2 && MAXHI <= 7, "");
-    constexpr int NSTEP = 4 * NSUB;                 // k-steps (8 channels) per chunk
-    static_assert(!APF || TMW == 1, "A prefetch is implemented for TMW = 1");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][32]; reused by the epilogue exchange
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int xi = wave & 3;
-    const int wn = wave >> 2;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int mblk, nblk;
-    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-
-    // LDS image of the halo: pixel hp (= image-local row Y, column X of the (TH+2) x (TW+2) halo) owns ROWF floats.
-    // Lanes of one ds_read_b128 group are a 4 x 4 block of Winograd tiles, i.e. pixels 2 apart in X and Y with the
-    // same parity, so the 16-byte slot is XOR-swizzled with a key built from the TILE coordinates
-    // key = ((Y>>1)&3)<<2 | ((X>>1)&3): 16 distinct keys per group -> conflict-free.  For 128-byte pixel rows the
-    // pixel parity is the 4th slot bit (two pixels share a 256-byte bank row; both have the same key).
-    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {
-        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
-        if (SPR == 8) return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
-        return hp * ROWF + ((slot ^ key) << 2);
-    };
-    const int hslot = tid % SPR;
-    const int hrow0 = tid / SPR;
-    int gpix[MAXHI], hoff[MAXHI];
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) {
-        const int hp = hrow0 + k * (NT / SPR);
-        int g = -1, ho = -1;
-        if (hp < HP) {
-            const int li = hp / HPI;
-            const int rem = hp - li * HPI;
-            const int hy = rem / HW;
-            const int hx = rem - hy * HW;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-            ho = lds_off(hp, hy, hx, hslot);
-        }
-        gpix[k] = g;
-        hoff[k] = ho;
-    }
-    const int Ctot = p.C0 + p.C1;
-    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
-
-    // fused GroupNorm: this thread always loads the same 4 channels of a chunk, so one coefficient pair per chunk
-    const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
-    auto load_gn = [&](int ch, f32x4& cA, f32x4& cB) {
-        cA = f32x4{1.f, 1.f, 1.f, 1.f};
-        cB = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int c = ch * ROWF + (hslot << 2);
-        if (p.gnA && c < Ctot) {
-            cA = *reinterpret_cast<const f32x4*>(p.gnA + (size_t)gimg * p.ld_gn + c);
-            cB = *reinterpret_cast<const f32x4*>(p.gnB + (size_t)gimg * p.ld_gn + c);
-        }
-    };
-    f32x4 gA, gB;            // coefficients of the chunk whose halo is being fetched
-    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = ch * ROWF + (hslot << 2);
-        if (g >= 0 && c < Ctot) {
-            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
-            v = *reinterpret_cast<const f32x4*>(src);
-            if (p.gnA) {
-                v = v * gA + gB;
-                if (p.gn_silu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
-                }
-            }
-        }
-        return v;
-    };
-    auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        if (hoff[k] >= 0) *reinterpret_cast<f32x4*>(smem + buf * (HP * ROWF) + hoff[k]) = v;
-    };
-
-    // (B^T d)[xi][j] = d[ra][j] + sgn * d[rb][j]:  xi=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
-    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
-    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
-    const float sgn = (xi == 1) ? 1.f : -1.f;
-
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    // LDS float offsets (k-step 0) of the 2 x 4 patch entries this lane reads per M tile; k-step kc is offset ^ (kc << 3)
-    // because the slot index (kc << 1 | lh) only differs in bits 1-2 and the swizzle is an XOR
-    int off_a[TMW][4], off_b[TMW][4];
-#pragma unroll
-    for (int mt = 0; mt < TMW; ++mt) {
-        const int t = mt * 32 + l31;
-        const int t_li = t >> (thl2 + twl2);
-        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-        const int t_x = t & ((1 << twl2) - 1);
-        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            off_a[mt][j] = lds_off(base + ra * HW + j, 2 * t_y + ra, 2 * t_x + j, lh);
-            off_b[mt][j] = lds_off(base + rb * HW + j, 2 * t_y + rb, 2 * t_x + j, lh);
-        }
-    }
-
-    int ntile = nblk * WNT + wn;
-    if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
-    // this wave's 4 fragments of k-step kc: positions 4*xi .. 4*xi+3 -> contiguous 4 KiB
-    const float* bp = p.w + ((size_t)ntile * FRAGS + 4 * xi) * 256 + lane * 4;
-    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
-
-    f32x16 acc[TMW][4];
-#pragma unroll
-    for (int mt = 0; mt < TMW; ++mt)
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mt][nu][e] = 0.f;
-
-    f32x4 bfr[2][4];      // [k-step parity][nu]
-    auto load_b = [&](f32x4 (&dst)[4], int c32, int kc) {
-        const float* q = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
-#if !defined(ND_WABL_NOB)
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = *reinterpret_cast<const f32x4*>(q + nu * 256);
-#else
-        asm volatile("" :: "v"(q));
-#endif
-    };
-    // raw patch entries (2 rows x 4 columns per M tile) of k-step st of the chunk staged at hbuf
-    auto read_patch = [&](const float* hbuf, int st, int mt, f32x4 (&da)[4], f32x4 (&db)[4]) {
-        int kx = st << 3;
-        asm volatile("" : "+s"(kx));          // keep the per-step addresses from being hoisted into registers
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#if !defined(ND_WABL_NOA)
-            da[j] = *reinterpret_cast<const f32x4*>(hbuf + (off_a[mt][j] ^ kx));
-            db[j] = *reinterpret_cast<const f32x4*>(hbuf + (off_b[mt][j] ^ kx));
-#else
-            da[j] = f32x4{(float)(off_a[mt][j] ^ kx), 1.f, 2.f, 3.f};
-            db[j] = f32x4{(float)(off_b[mt][j] ^ kx), 1.f, 2.f, 3.f};
-#endif
-        }
-    };
-
-    load_gn(0, gA, gB);
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
-    load_b(bfr[0], 0, 0);
-    __syncthreads();
-
-    f32x4 pa[2][4], pb[2][4];      // raw patch rows ra / rb of the A-prefetch form, [k-step parity]
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
-        const bool halo_next = (ch + 1) < nchunks;
-        load_gn(ch + 1, gA, gB);                 // every halo fetch of this iteration is for chunk ch + 1
-        int nvalid = (p.NC32 - ch * NSUB) * 4;          // k-steps of this chunk that hold real channels
-        if (nvalid > NSTEP) nvalid = NSTEP;
-        f32x4 phb[HB];
-        if constexpr (APF) read_patch(hbuf, 0, 0, pa[0], pb[0]);
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st < nvalid) {
-                const int cur = st & 1, nxt = cur ^ 1;
-                // B fragments of the next k-step (the stream has a zero block of padding at the end)
-                if (st + 1 < NSTEP) load_b(bfr[nxt], ch * NSUB + ((st + 1) >> 2), (st + 1) & 3);
-                else load_b(bfr[nxt], (ch + 1) * NSUB, 0);
-                if (st == 0 || st == NSTEP / 2) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st ? HB : 0) + i;
-                        if (k < MAXHI && k < p.nhi) {
-#if defined(ND_WABL_HALOHIT)
-                            phb[i] = load_halo_pixel(halo_next ? (gpix[k] & 1023) : -1, ch + 1);
-#elif !defined(ND_WABL_NOHALO)
-                            phb[i] = load_halo_pixel(halo_next ? gpix[k] : -1, ch + 1);
-#else
-                            phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-                        }
-                    }
-                }
-                if constexpr (APF) {
-                    if (st + 1 < NSTEP) read_patch(hbuf, st + 1, 0, pa[nxt], pb[nxt]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < TMW; ++mt) {
-                    f32x4 v[4];
-                    {
-                        f32x4 tr[4];
-                        if constexpr (APF) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) tr[j] = pa[cur][j] + sgn * pb[cur][j];
-                        } else {
-                            f32x4 da[4], db[4];
-                            read_patch(hbuf, st, mt, da, db);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) tr[j] = da[j] + sgn * db[j];
-                        }
-                        v[0] = tr[0] - tr[2];
-                        v[1] = tr[1] + tr[2];
-                        v[2] = tr[2] - tr[1];
-                        v[3] = tr[1] - tr[3];
-                    }
-#if !defined(ND_WINO_J_OUTER)   // 4 back-to-back MFMAs per accumulator: measured 30 % faster than interleaving them
-#pragma unroll
-                    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][nu][j], v[nu][j], acc[mt][nu], 0, 0, 0);
-#else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int nu = 0; nu < 4; ++nu)
-                            acc[mt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][nu][j], v[nu][j], acc[mt][nu], 0, 0, 0);
-#endif
-                }
-                if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st == 1 ? 0 : HB) + i;
-#if defined(ND_WABL_NOSTORE)
-                        if (k < MAXHI && k < p.nhi) asm volatile("" :: "v"(phb[i][0]), "v"(phb[i][3]));
-#else
-                        if (k < MAXHI && k < p.nhi) store_halo_item(k, (ch + 1) & 1, phb[i]);
-#endif
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- epilogue.  The MFMAs were issued as M^T = U . V^T (weights as the A operand), so in the C/D layout a lane owns
-    //      ONE Winograd tile (col = lane&31) and 4 consecutive output channels per register group.
-    //      r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]) is formed in registers and exchanged
-    //      through LDS as ex[wn][xi][b][group][lane][4]; then wave xi finishes register group xi for all four xi:
-    //      Y[a][b] = sum_xi At[a][xi] r_xi[b], i.e. 2x2 output pixels x 4 channels per lane -> 16-byte stores.
-    float* ex = smem;
-    const int nb = n0 + wn * 32 + 8 * xi + 4 * lh;          // first of this lane's 4 output channels
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (nb + c < p.N) bv[c] = p.bias[nb + c];
-    }
-    const bool vec = p.vec_ok && (nb + 3 < p.N);
-#pragma unroll
-    for (int mt = 0; mt < TMW; ++mt) {
-        __syncthreads();        // halo / previous round fully consumed
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 r0, r1;
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) {
-                const int e = 4 * g4 + ee;
-                r0[ee] = acc[mt][0][e] + acc[mt][1][e] + acc[mt][2][e];
-                r1[ee] = acc[mt][1][e] - acc[mt][2][e] - acc[mt][3][e];
-            }
-            *reinterpret_cast<f32x4*>(ex + ((((wn * 4 + xi) * 2 + 0) * 4 + g4) * 64 + lane) * 4) = r0;
-            *reinterpret_cast<f32x4*>(ex + ((((wn * 4 + xi) * 2 + 1) * 4 + g4) * 64 + lane) * 4) = r1;
-        }
-        __syncthreads();
-        f32x4 rr[4][2];
-#pragma unroll
-        for (int x2 = 0; x2 < 4; ++x2)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-                rr[x2][b2] = *reinterpret_cast<const f32x4*>(ex + ((((wn * 4 + x2) * 2 + b2) * 4 + xi) * 64 + lane) * 4);
-        const int te = mt * 32 + l31;
-        const int li = te >> (thl2 + twl2);
-        const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-        const int txx = te & ((1 << twl2) - 1);
-        const int img = img0 + li;
-        if (nb < p.N && img < p.NI) {
-            f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
-            if (p.rowbias) {
-                const float* rb = p.rowbias + (size_t)img * p.ld_rowbias + nb;
-                if (vec) rbv = *reinterpret_cast<const f32x4*>(rb);
-                else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (nb + c < p.N) rbv[c] = rb[c];
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    f32x4 yv = (a == 0) ? (rr[0][b2] + rr[1][b2] + rr[2][b2]) : (rr[1][b2] - rr[2][b2] - rr[3][b2]);
-                    const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
-                    if (oy < p.H && ox < p.W) {
-                        yv = yv + bv;
-                        if (p.rowbias) yv += rbv;
-                        float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
-                        const float* rp = nullptr;
-                        if (p.res) {
-                            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                        : ((size_t)(img * p.H + oy) * p.W + ox);
-                            rp = p.res + rpx * p.ldr + nb;
-                        }
-                        if (vec) {
-                            if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
-                            if (p.silu_out) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
-                            }
-                            *reinterpret_cast<f32x4*>(op) = yv;
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                if (nb + c < p.N) {
-                                    float v2 = yv[c];
-                                    if (rp) v2 += rp[c];
-                                    if (p.silu_out) v2 = fast_silu(v2);
-                                    op[c] = v2;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Position-split form of the Winograd kernel: 16 waves (4 per SIMD, <= 128 VGPRs), wave w owns ONE of the 16 transform
-// positions (xi = w >> 2, nu = w & 3) for all three 32-channel n tiles of a 128 px x 96 ch block.  Per k-step a wave
-// needs one transformed A fragment (4 raw ds_read_b128 + 3 vector adds instead of 8 + 8 for a whole transform row), three
-// weight fragments and 12 MFMAs; 48 accumulator registers per wave leave room for a fourth wave per SIMD to hide the
-// L2 / LDS latency the 12-wave form stalls on.  All 16 positions of a tile now live in different waves, so the output
-// transform runs through LDS for one n tile at a time (two 64 KiB exchange buffers, three rounds); the association
-// order of the sums is the one of conv_wino_kernel, so both forms give the same bits.
-template <int NSUB>
-__global__ void __launch_bounds__(1024, 4)
-    conv_wino16_kernel(const ConvArgs p) {
-    constexpr int NT = 1024, WNT = 3, BN = 96;
-    constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
-    constexpr int FRAGS = 64;
-    constexpr int HPMAX = 208;
-    constexpr int MAXHI = (HPMAX * SPR + NT - 1) / NT;      // 2 (NSUB 1) or 4 (NSUB 2)
-    constexpr int HB = (MAXHI + 1) / 2;
-    constexpr int NSTEP = 4 * NSUB;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // = transform position 4*xi + nu
-    const int xi = wave >> 2;
-    const int nu = wave & 3;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int mblk, nblk;
-    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-
-    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel
-        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
-        if (SPR == 8) return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
-        return hp * ROWF + ((slot ^ key) << 2);
-    };
-    const int hslot = tid % SPR;
-    const int hrow0 = tid / SPR;
-    int gpix[MAXHI], hoff[MAXHI];
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) {
-        const int hp = hrow0 + k * (NT / SPR);
-        int g = -1, ho = -1;
-        if (hp < HP) {
-            const int li = hp / HPI;
-            const int rem = hp - li * HPI;
-            const int hy = rem / HW;
-            const int hx = rem - hy * HW;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-            ho = lds_off(hp, hy, hx, hslot);
-        }
-        gpix[k] = g;
-        hoff[k] = ho;
-    }
-    const int Ctot = p.C0 + p.C1;
-    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
-
-    // (this form does not fold GroupNorm into the loader: the host refuses gnA for it)
-    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = ch * ROWF + (hslot << 2);
-        if (g >= 0 && c < Ctot) {
-            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
-            v = *reinterpret_cast<const f32x4*>(src);
-        }
-        return v;
-    };
-    auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        if (hoff[k] >= 0) *reinterpret_cast<f32x4*>(smem + buf * (HP * ROWF) + hoff[k]) = v;
-    };
-
-    // V[xi][nu] = sum_{a,b} Bt[xi][a] d[a][b] Bt[nu][b]; every row of Bt has two non-zeros (+-1):
-    //   index 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
-    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
-    const float sgr = (xi == 1) ? 1.f : -1.f;
-    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
-    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
-    const float sgc = (nu == 1) ? 1.f : -1.f;
-
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    int off4[4];          // LDS float offsets (k-step 0) of d[ra][ca], d[rb][ca], d[ra][cb], d[rb][cb] of this lane's tile
-    {
-        const int t = l31;
-        const int t_li = t >> (thl2 + twl2);
-        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-        const int t_x = t & ((1 << twl2) - 1);
-        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
-        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
-        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
-        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
-    }
-
-    // weight fragments of this position for the three n tiles (N tail: clamped, results dropped in the epilogue)
-    const int ntile0 = nblk * WNT;
-    const float* bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
-    int noff[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        int nt_ = ntile0 + rr;
-        if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
-        noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
-    }
-    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
-
-    f32x16 acc[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
-
-    f32x4 bfr[2][WNT];
-    auto load_b = [&](f32x4 (&dst)[WNT], int c32, int kc) {
-        const float* qq = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
-#if !defined(ND_WABL_NOB)
-#pragma unroll
-        for (int rr = 0; rr < WNT; ++rr) dst[rr] = *reinterpret_cast<const f32x4*>(qq + noff[rr]);
-#else
-        asm volatile("" :: "v"(qq));
-#endif
-    };
-
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k)
-        if (k < p.nhi) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
-    load_b(bfr[0], 0, 0);
-    __syncthreads();
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
-        const bool halo_next = (ch + 1) < nchunks;
-        int nvalid = (p.NC32 - ch * NSUB) * 4;
-        if (nvalid > NSTEP) nvalid = NSTEP;
-        f32x4 phb[HB];
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st < nvalid) {
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < NSTEP) load_b(bfr[nxt], ch * NSUB + ((st + 1) >> 2), (st + 1) & 3);
-                else load_b(bfr[nxt], (ch + 1) * NSUB, 0);
-                if (st == 0 || st == NSTEP / 2) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st ? HB : 0) + i;
-#if !defined(ND_WABL_NOHALO)
-                        if (k < MAXHI && k < p.nhi) phb[i] = load_halo_pixel(halo_next ? gpix[k] : -1, ch + 1);
-#else
-                        if (k < MAXHI && k < p.nhi) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-                    }
-                }
-                // (no sched_barrier here: letting the compiler interleave the loads with the previous MFMAs measures 1-2 % faster)
-                f32x4 v;
-                {
-                    int kx = st << 3;
-                    asm volatile("" : "+s"(kx));
-#if !defined(ND_WABL_NOA)
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
-                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
-                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
-#else
-                    const f32x4 d0 = f32x4{(float)(off4[0] ^ kx), 1.f, 2.f, 3.f}, d1 = f32x4{(float)(off4[1] ^ kx), 1.f, 2.f, 3.f};
-                    const f32x4 d2 = f32x4{(float)(off4[2] ^ kx), 1.f, 2.f, 3.f}, d3 = f32x4{(float)(off4[3] ^ kx), 1.f, 2.f, 3.f};
-#endif
-                    const f32x4 ta = d0 + sgr * d1;          // tr[ca]
-                    const f32x4 tb = d2 + sgr * d3;          // tr[cb]
-                    v = ta + sgc * tb;
-                }
-#pragma unroll
-                for (int rr = 0; rr < WNT; ++rr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][rr][j], v[j], acc[rr], 0, 0, 0);
-                }
-                if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st == 1 ? 0 : HB) + i;
-                        if (k < MAXHI && k < p.nhi) store_halo_item(k, (ch + 1) & 1, phb[i]);
-                    }
-                }
-            }
-        }
-#if !defined(ND_WABL_NOBARRIER)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#endif
-    }
-
-#if defined(ND_WABL_NOEPI)
-    if (acc[0][0] == 123.456f && acc[1][3] == 1.5f && acc[2][7] == 2.5f) p.out[0] = 1.f;
-    return;
-#endif
-    // ---- epilogue: three rounds (one per n tile) through two exchange buffers ex[buf][pos][group][lane][4].
-    //      Accumulators are M^T (row = channel, col = tile): register group g4 of a lane = 4 consecutive channels of its
-    //      tile.  Reader wave w finishes output pixel (a, b) = (w >> 3, (w >> 2) & 1) of channel group g4 = w & 3:
-    //      Y[a][b] = sum_xi At[a][xi] (sum_nu At[b][nu] M[xi][nu]),  At = [[1,1,1,0],[0,1,-1,-1]].
-    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
-    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
-    const int te = l31;
-    const int li = te >> (thl2 + twl2);
-    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-    const int txx = te & ((1 << twl2) - 1);
-    const int img = img0 + li;
-    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
-    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
-    // residual rows of the three rounds are fetched now, so that their HBM latency hides behind the LDS exchange
-    f32x4 resv[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
-        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
-            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                        : ((size_t)(img * p.H + oy) * p.W + ox);
-            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
-        }
-    }
-    __syncthreads();            // last chunk's halo fully consumed
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        {
-            // round rr+2 reuses this buffer: every wave has passed the barrier of round rr+1 by then, i.e. finished
-            // reading round rr
-            float* exw = smem + (rr & 1) * (16 * 4 * 256);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
-            }
-        }
-        __syncthreads();
-        {
-            const float* exr = smem + (rr & 1) * (16 * 4 * 256);
-            f32x4 rx[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int x2 = pa + i;
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
-                rx[i] = (m0 + sb * m1) + sb * m2;
-            }
-            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
-            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
-            f32x4 fin = {0.f, 0.f, 0.f, 0.f};          // what was stored (zeros for lanes / channels that store nothing)
-            if (pix_ok && nb < p.N) {
-                const bool vec = p.vec_ok && (nb + 3 < p.N);
-                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
-                const float* rp = nullptr;
-                if (p.res) {
-                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                : ((size_t)(img * p.H + oy) * p.W + ox);
-                    rp = p.res + rpx * p.ldr + nb;
-                }
-                if (vec) {
-                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
-                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    yv += resv[rr];           // zeros without a residual
-                    if (p.silu_out) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = yv;
-                    fin = yv;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (nb + c < p.N) {
-                            float v2 = yv[c];
-                            if (p.bias) v2 += p.bias[nb + c];
-                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
-                            if (rp) v2 += rp[c];
-                            if (p.silu_out) v2 = fast_silu(v2);
-                            op[c] = v2;
-                            fin[c] = v2;
-                        }
-                    }
-                }
-            }
-            if (p.chstats) {
-                // GroupNorm statistics of the output for free: per-channel sum / sum of squares over this wave's pixels of
-                // each image (the tiles of one image are a power-of-two run of lanes), stored as one partial row per
-                // (image, m block, pixel-wave): no atomics, and the consumer reads N floats x 8 x m-blocks per image
-                // instead of the whole tensor.
-                f32x4 sq = fin * fin;
-                const int gl = 1 << (thl2 + twl2);          // tiles (= lanes of a half-wave) per image
-                for (int m = 1; m < gl; m <<= 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        fin[c] += __shfl_xor(fin[c], m);
-                        sq[c] += __shfl_xor(sq[c], m);
-                    }
-                }
-                if ((l31 & (gl - 1)) == 0 && img < p.NI && nb < p.N) {
-                    const int mb = (p.nibl == 0) ? (ty * p.tiles_x + tx) : 0;
-                    float* ps = p.chstats + ((((size_t)img * p.mbi + mb) * 4 + (wave >> 2)) * 2) * p.N + nb;
-                    if (nb + 3 < p.N && (p.N & 3) == 0) {
-                        *reinterpret_cast<f32x4*>(ps) = fin;
-                        *reinterpret_cast<f32x4*>(ps + p.N) = sq;
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (nb + c < p.N) {
-                                ps[c] = fin[c];
-                                ps[p.N + c] = sq[c];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-#define ND_GLDS16(gptr, lptr)                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-__global__ void __launch_bounds__(1024, 4)
-    conv_wino16g_kernel(const ConvArgs p) {
-    constexpr int WNT = 3, BN = 96;
-    constexpr int ROWF = 32;
-    constexpr int FRAGS = 64;
-    constexpr int HUNITS = 2048;                 // 16-byte units per halo buffer = 2 DMAs x 16 waves x 64 lanes
-    constexpr int HBUF = HUNITS * 4;             // floats
-    constexpr int RING0 = 2 * HBUF;              // float offset of the weight ring
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // = transform position 4*xi + nu
-    const int xi = wave >> 2;
-    const int nu = wave & 3;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int mblk, nblk;
-    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-
-    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel (SPR = 8)
-        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
-        return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
-    };
-
-    // ---- halo DMA descriptors.  DMA k of this wave fills units (k*16 + wave)*64 + lane of the buffer; unit U is slot
-    //      s' = U & 15 of the 256-byte row of pixel pair U >> 4; un-swizzling gives the pixel and channel slot it holds.
-    const int Ctot = p.C0 + p.C1;
-    int gpx[2], hsl[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int U = (k * 16 + wave) * 64 + lane;
-        const int pp = U >> 4;
-        const int hp0 = pp * 2;
-        int g = -1, sl = 0;
-        if (hp0 < HP) {
-            const int li = hp0 / HPI;
-            const int rem = hp0 - li * HPI;
-            const int hy = rem / HW;
-            const int hx0 = rem - hy * HW;              // even; the pair (hx0, hx0 + 1) shares the swizzle key
-            const int key = (((hy >> 1) & 3) << 2) | ((hx0 >> 1) & 3);
-            const int t = (U & 15) ^ key;
-            const int hx = hx0 + (t >> 3);
-            sl = t & 7;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-        }
-        gpx[k] = g;
-        hsl[k] = sl << 2;
-    }
-    const float* zero16 = p.zero;
-    auto halo_src = [&](int k, int ch) -> const float* {
-        const int c = ch * ROWF + hsl[k];
-        const int g = gpx[k];
-        const float* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
-                                      : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
-        return (g >= 0 && c < Ctot) ? src : zero16;
-    };
-    auto issue_halo = [&](int ch, int buf) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) ND_GLDS16(halo_src(k, ch), smem + buf * HBUF + (k * 16 + wave) * 256);
-    };
-
-    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
-    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
-    const float sgr = (xi == 1) ? 1.f : -1.f;
-    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
-    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
-    const float sgc = (nu == 1) ? 1.f : -1.f;
-
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    int off4[4];
-    {
-        const int t = l31;
-        const int t_li = t >> (thl2 + twl2);
-        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-        const int t_x = t & ((1 << twl2) - 1);
-        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
-        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
-        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
-        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
-    }
-
-    const int ntile0 = nblk * WNT;
-    const float* bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
-    int noff[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        int nt_ = ntile0 + rr;
-        if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
-        noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
-    }
-    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
-    float* ring = smem + RING0 + wave * (2 * WNT * 256);      // this wave's 2 slots x 3 fragments
-    // fragments of global k-step gs = 4*c32 + kc go to ring slot gs & 1
-    auto issue_b = [&](int gs) {
-        const float* qq = bp + (size_t)(gs >> 2) * c32_stride + (gs & 3) * (16 * 256);
-#pragma unroll
-        for (int rr = 0; rr < WNT; ++rr) ND_GLDS16(qq + noff[rr], ring + ((gs & 1) * WNT + rr) * 256);
-    };
-
-    f32x16 acc[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
-
-    const int nchunks = p.NC32;
-    issue_halo(0, 0);
-    issue_b(0);
-    issue_b(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // VMEM issue order inside chunk ch (k-steps g = 4*ch + st):   st=0: B(g+2), H(ch+1) x2;  st=1..3: B(g+2).
-    // Before reading B(g) (issued two steps earlier) the younger operations allowed in flight are B(g+1) and whatever was
-    // issued between them:  st=0: 3;  st=1: 3 + 2 halo;  st=2: 2 halo + 3;  st=3: 3.
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * HBUF;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int gs = ch * 4 + st;
-            if (st == 0 || st == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            f32x4 bfr[WNT];
-#pragma unroll
-            for (int rr = 0; rr < WNT; ++rr)
-                bfr[rr] = *reinterpret_cast<const f32x4*>(ring + ((st & 1) * WNT + rr) * 256 + lane * 4);
-            const int kx = st << 3;
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
-            const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
-            const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot (gs & 1) has been read: refill it
-            issue_b(gs + 2);                                       // (a partial lgkmcnt(4) here measured 10 % slower)
-            if (st == 0) issue_halo(ch + 1, (ch + 1) & 1);          // past the last chunk: zero block (c >= Ctot)
-            const f32x4 ta = d0 + sgr * d1;
-            const f32x4 tb = d2 + sgr * d3;
-            const f32x4 v = ta + sgc * tb;
-#pragma unroll
-            for (int rr = 0; rr < WNT; ++rr) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[rr][j], v[j], acc[rr], 0, 0, 0);
-            }
-        }
-        // next chunk's halo (issued at st = 0, followed by 9 weight DMAs) must have landed before anyone reads it
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // run-ahead weight DMAs still target the ring
-    __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue: identical to conv_wino16_kernel
-    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
-    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
-    const int te = l31;
-    const int li = te >> (thl2 + twl2);
-    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-    const int txx = te & ((1 << twl2) - 1);
-    const int img = img0 + li;
-    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
-    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
-    f32x4 resv[WNT];           // residual rows, fetched ahead of the LDS exchange (see conv_wino16_kernel)
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
-        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
-            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                        : ((size_t)(img * p.H + oy) * p.W + ox);
-            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        {
-            float* exw = smem + (rr & 1) * (16 * 4 * 256);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
-            }
-        }
-        __syncthreads();
-        {
-            const float* exr = smem + (rr & 1) * (16 * 4 * 256);
-            f32x4 rx[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int x2 = pa + i;
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
-                rx[i] = (m0 + sb * m1) + sb * m2;
-            }
-            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
-            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
-            if (pix_ok && nb < p.N) {
-                const bool vec = p.vec_ok && (nb + 3 < p.N);
-                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
-                const float* rp = nullptr;
-                if (p.res) {
-                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                : ((size_t)(img * p.H + oy) * p.W + ox);
-                    rp = p.res + rpx * p.ldr + nb;
-                }
-                if (vec) {
-                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
-                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    yv += resv[rr];
-                    if (p.silu_out) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = yv;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (nb + c < p.N) {
-                            float v2 = yv[c];
-                            if (p.bias) v2 += p.bias[nb + c];
-                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
-                            if (rp) v2 += rp[c];
-                            if (p.silu_out) v2 = fast_silu(v2);
-                            op[c] = v2;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
-__global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(it & 3);
-        const int lane = (int)((it >> 2) & 63);
-        long r = it >> 8;
-        const int ps = (int)(r & 15);
-        r >>= 4;
-        const int kc = (int)(r & 3);
-        r >>= 2;
-        const int ntile = (int)(r % NT32);
-        const int c32 = (int)(r / NT32);
-        const int n = ntile * 32 + (lane & 31);
-        const int c = c32 * 32 + kc * 8 + (lane >> 5) * 4 + j;
-        float u = 0.f;
-        if (n < N && c < C) {
-            const float* g = w + ((size_t)n * C + c) * 9;
-            const int xi = ps >> 2, nu = ps & 3;
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) u += G[xi][a] * g[a * 3 + b] * G[nu][b];
-        }
-        out[it] = u;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // host side: tile-shape variants and launch
 // ------------------------------------------------------------------------------------------------------------
 struct Variant {
@@ -1756,16 +685,6 @@ static int dispatch(int v, const ConvArgs& a, int grid, size_t lds, hipStream_t 
     return ND_E_ARG;
 }
 
-struct TilePlan {
-    int thl, twl, nibl, tiles_x, tiles_y, groups, hp;
-    long padded;   // padded pixel count
-};
-
-static int ilog2(int v) {
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
 
 static size_t lds_bytes(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 32 : 64) * sizeof(float); }
 
@@ -1964,234 +883,3 @@ extern "C" int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads)
     return ND_OK;
 }
 
-// ---- Winograd F(2x2,3x3) entry points -------------------------------------------------------------------------
-namespace nd {
-// {M tiles of 32 Winograd tiles (= 128 output pixels) per block, 32-channel sub-chunks per LDS chunk, A prefetch,
-//  n tiles of 32 channels per block (4 waves each)}
-static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 2, 1, 2}, {1, 2, 0, 2}, {1, 1, 0, 1}, {1, 2, 0, 3}, {1, 1, 0, 3},
-                                 // position-split form (conv_wino16_kernel): 16 waves, 96 channels; coded as WN = 4
-                                 {1, 1, 0, 4},
-                                 // + LDS-DMA operand streams (conv_wino16g_kernel); coded as WN = 5
-                                 {1, 1, 0, 5}};
-static constexpr int kNumWino = 10;
-static constexpr int kStatsVariant = 8;        // conv_wino16_kernel: the one whose epilogue can emit output statistics
-
-template <int TMW, int NSUB, bool APF, int WNT>
-static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino_kernel<TMW, NSUB, APF, WNT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WNT), lds, s, a);
-    return check_launch("nd_conv3x3_winograd_nhwc");
-}
-
-template <int NSUB>
-static int launch_wino16(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_wino16_kernel<NSUB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, a);
-    return check_launch("nd_conv3x3_winograd_nhwc");
-}
-
-}  // namespace nd
-
-extern "C" int nd_conv_winograd_num_variants(void) { return kNumWino; }
-
-extern "C" const char* nd_conv_winograd_variant_name(int variant) {
-    static const char* names[] = {"nd::conv_wino_kernel<2, 1, false, 2>", "nd::conv_wino_kernel<1, 1, false, 2>",
-                                  "nd::conv_wino_kernel<1, 1, true, 2>",  "nd::conv_wino_kernel<1, 2, true, 2>",
-                                  "nd::conv_wino_kernel<1, 2, false, 2>", "nd::conv_wino_kernel<1, 1, false, 1>",
-                                  "nd::conv_wino_kernel<1, 2, false, 3>", "nd::conv_wino_kernel<1, 1, false, 3>",
-                                  "nd::conv_wino16_kernel<1>",            "nd::conv_wino16g_kernel"};
-    static_assert(sizeof(names) / sizeof(names[0]) == kNumWino, "one name per variant");
-    return (variant < 0 || variant >= kNumWino) ? "" : names[variant];
-}
-
-extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, int* nsub, int* apf) {
-    if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
-    if (bm) *bm = kWinoCfg[variant][0] * 128;
-    const bool split = kWinoCfg[variant][3] >= 4;
-    if (bn) *bn = split ? 96 : kWinoCfg[variant][3] * 32;
-    if (threads) *threads = split ? 1024 : kWinoCfg[variant][3] * 256;
-    if (nsub) *nsub = kWinoCfg[variant][1];
-    if (apf) *apf = kWinoCfg[variant][2];
-    return ND_OK;
-}
-
-extern "C" int64_t nd_conv_winograd_weight_floats(int N, int C) {
-    if (N <= 0 || C <= 0) return ND_E_ARG;
-    return (int64_t)((C + 31) / 32 + 1) * ((N + 31) / 32) * 64 * 256;
-}
-
-extern "C" int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream) {
-    const char* fn = "nd_repack_conv_weight_winograd";
-    ND_REQUIRE(w_oihw && w_out && N > 0 && C > 0, fn, "bad arguments");
-    const long total = (long)nd_conv_winograd_weight_floats(N, C);
-    long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_oihw,
-                       w_out, N, C, (N + 31) / 32, total);
-    return check_launch(fn);
-}
-
-// Winograd block region = WM*32 tiles = WM*128 output pixels as NIB x TH x TW with TH, TW >= 2: fewest padded pixels,
-// then smallest halo
-static bool wino_tiles(int WM, int nsub, int hpmax, int NI, int H, int W, TilePlan* out) {
-    const int bm = WM * 128;
-    const int lbm = ilog2(bm);
-    TilePlan best{};
-    bool found = false;
-    for (int twl = 1; twl <= lbm; ++twl) {
-        for (int thl = 1; thl + twl <= lbm; ++thl) {
-            const int nibl = lbm - twl - thl;
-            const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
-            const int hp = NIB * (TH + 2) * (TW + 2);
-            if (hp > hpmax) continue;
-            if ((size_t)2 * hp * 128 * nsub > 160 * 1024) continue;
-            TilePlan t;
-            t.thl = thl; t.twl = twl; t.nibl = nibl;
-            t.tiles_x = (W + TW - 1) / TW; t.tiles_y = (H + TH - 1) / TH; t.groups = (NI + NIB - 1) / NIB;
-            t.hp = hp;
-            t.padded = (long)t.tiles_x * t.tiles_y * t.groups * bm;
-            if (!found || t.padded < best.padded || (t.padded == best.padded && t.hp < best.hp)) { best = t; found = true; }
-        }
-    }
-    if (found) *out = best;
-    return found;
-}
-
-static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                       const float* w, const float* bias, const float* rowbias, int ld_rowbias,
-                       const float* residual, int ldr, float* out, int ldo,
-                       int NI, int H, int W, int N, int flags, int variant,
-                       const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream) {
-    const char* fn = "nd_conv3x3_winograd_nhwc";
-    ND_REQUIRE(x0 && w && out, fn, "null pointer");
-    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
-    ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "Winograd F(2x2,3x3) needs even H and W");
-    ND_REQUIRE((C0 & 3) == 0 && (C1 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && ldo >= N, fn, "channels / strides");
-    ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
-    if (C1 > 0) ND_REQUIRE(x1 != nullptr && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn, "x1");
-    if (flags & ND_CONV_SILU_OUT) ND_REQUIRE(residual == nullptr, fn, "SILU_OUT with a residual is not supported");
-    if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
-    if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
-    ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
-    ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
-    const bool split = kWinoCfg[variant][3] >= 4;
-    const bool dma = kWinoCfg[variant][3] == 5;
-    const int WM = kWinoCfg[variant][0], WN = split ? 3 : kWinoCfg[variant][3];
-    const int nsub = kWinoCfg[variant][1];
-    const int nt = split ? 1024 : 256 * WN;
-    const int hpmax = (WM == 2) ? 384 : ((WN == 3) ? 208 : 192);   // = the kernel's HPMAX
-    TilePlan best{};
-    const bool found = wino_tiles(WM, nsub, hpmax, NI, H, W, &best);
-    if (!found) return fail_arg(fn, "no tiling fits this shape");
-    const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
-    ConvArgs a;
-    a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
-    a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
-    a.NI = NI; a.H = H; a.W = W; a.up = up; a.res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;
-    a.Hs = H >> up; a.Ws = W >> up;
-    a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
-    a.NT32 = (N + 31) / 32; a.NC32 = (C0 + C1 + 31) / 32;
-    a.thl = best.thl; a.twl = best.twl; a.nibl = best.nibl;
-    a.tiles_x = best.tiles_x; a.tiles_y = best.tiles_y;
-    a.mt = best.tiles_x * best.tiles_y * best.groups;
-    a.nt = (N + WN * 32 - 1) / (WN * 32);
-    a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float));
-    a.nhi = (best.hp * 8 * nsub + nt - 1) / nt;
-    a.vec_ok = ((ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
-                (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
-                (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias)))) ? 1 : 0;
-    a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
-    a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
-    if (gnA) {
-        ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1 && (ld_gn & 3) == 0 && aligned16(gnA) && aligned16(gnB), fn,
-                   "fused GroupNorm: bad coefficient arrays");
-        ND_REQUIRE(best.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
-        ND_REQUIRE(!split, fn, "the position-split variants do not fold GroupNorm into the loader");
-    }
-    const int grid = a.mt * a.nt;
-    size_t lds = (size_t)2 * best.hp * 128 * nsub;
-    if (lds < (size_t)WN * 32 * 1024) lds = (size_t)WN * 32 * 1024;     // epilogue exchange: 4*WN waves x 2 x 16 x 64 floats
-    if (split && lds < (size_t)128 * 1024) lds = (size_t)128 * 1024;    // two 64 KiB exchange buffers
-    if (dma) lds = (size_t)160 * 1024;
-    a.zero = w + (nd_conv_winograd_weight_floats(N, C0 + C1) - 256);     // inside the zero padding block
-    a.chstats = chstats;
-    a.mbi = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
-    if (chstats) ND_REQUIRE(variant == kStatsVariant && ldo == N, fn, "output statistics: only the position-split variant produces them (and needs ldo == N)");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (variant) {
-        case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
-        case 1: return launch_wino<1, 1, false, 2>(a, grid, lds, s);
-        case 2: return launch_wino<1, 1, true, 2>(a, grid, lds, s);
-        case 3: return launch_wino<1, 2, true, 2>(a, grid, lds, s);
-        case 4: return launch_wino<1, 2, false, 2>(a, grid, lds, s);
-        case 5: return launch_wino<1, 1, false, 1>(a, grid, lds, s);
-        case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
-        case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
-        case 8: return launch_wino16<1>(a, grid, lds, s);
-        case 9: {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16g_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) {
-                    set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    return ND_E_LAUNCH;
-                }
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(conv_wino16g_kernel, dim3(grid), dim3(1024), lds, s, a);
-            return check_launch(fn);
-        }
-    }
-    return fail_arg(fn, "bad variant");
-}
-
-extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
-                                        const float* residual, int ldr, float* out, int ldo,
-                                        int NI, int H, int W, int N, int flags, int variant,
-                                        const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
-    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
-                       flags, variant, gnA, gnB, ld_gn, nullptr, stream);
-}
-
-extern "C" int nd_conv_winograd_stats_variant(void) { return kStatsVariant; }
-
-extern "C" int64_t nd_conv_winograd_stats_floats(int NI, int H, int W, int N, int* mbi) {
-    if (NI <= 0 || H <= 0 || W <= 0 || N <= 0 || (H & 1) || (W & 1)) return ND_E_ARG;
-    TilePlan best{};
-    if (!wino_tiles(1, 1, 208, NI, H, W, &best)) return ND_E_ARG;
-    const int m = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
-    if (mbi) *mbi = m;
-    return (int64_t)NI * m * 8 * N;
-}
-
-extern "C" int nd_conv3x3_winograd_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                                              const float* w, const float* bias, const float* rowbias, int ld_rowbias,
-                                              const float* residual, int ldr, float* out, int ldo,
-                                              int NI, int H, int W, int N, int flags,
-                                              float* chstats, nd_stream_t stream) {
-    if (!chstats) return fail_arg("nd_conv3x3_winograd_stats_nhwc", "chstats is null");
-    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
-                       flags, kStatsVariant, nullptr, nullptr, 0, chstats, stream);
-}
