@@ -6,7 +6,11 @@ calls on the current stream; it allocates nothing and never synchronises, so a c
 (``Diffusion.denoise`` does).  Reference counterpart: the module-by-module Python dispatch of
 ``DiffusionModel.forward`` (model.py:451-476) and ``UsesStepsSequential.forward`` (model.py:42-48).
 """
+import ctypes
+import json
 import math
+import os
+import time
 
 import torch
 
@@ -20,20 +24,16 @@ _TUNED = {}
 
 
 def _autotune_enabled():
-    import os
     return os.environ.get('ND_AUTOTUNE', '1') != '0'
 
 
 def _tune_cache_path():
-    import os
     return os.environ.get('ND_TUNE_CACHE')
 
 
 def _load_tune_cache():
     """Optional on-disk cache of the measured choices (ND_TUNE_CACHE=file.json): lets a second process (e.g. a run under
     rocprofv3) start without the tuning launches."""
-    import json
-    import os
     path = _tune_cache_path()
     if path and os.path.exists(path) and not _TUNED:
         try:
@@ -44,7 +44,6 @@ def _load_tune_cache():
 
 
 def _save_tune_cache():
-    import json
     path = _tune_cache_path()
     if path:
         json.dump({json.dumps(list(k)): list(v) for k, v in _TUNED.items()}, open(path, 'w'))
@@ -83,7 +82,6 @@ def _epilogue_stats_enabled():
     behind (nd_conv3x3_winograd_stats_nhwc + nd_groupnorm_stats_from_partials) instead of a statistics pass over the
     tensor.  Off by default: measured at B=64 it removes 1.0 ms of HBM-bound statistics kernels but the cross-lane
     reduction in the epilogue costs the MFMA-bound convs 2.2 ms (forward 76.8 vs 75.6 ms)."""
-    import os
     return os.environ.get('ND_GN_EPILOGUE_STATS', '0') == '1'
 
 
@@ -92,7 +90,6 @@ def _fuse_gn_mode():
     norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
     (~8x for 384 channels on the Winograd tiles), which costs 20-25 % of the conv and far exceeds the 3.4 ms of the
     separate HBM-bound apply pass, so SiLU norms keep their own kernel."""
-    import os
     return int(os.environ.get('ND_FUSE_GN', '1'))
 
 
@@ -260,7 +257,6 @@ class UNetPlan:
             if (want_stats and _epilogue_stats_enabled() and var == self.lib.nd_conv_winograd_stats_variant()
                     and gn[0] is None and out.ld == N):
                 # the position-split kernel leaves the next GroupNorm's statistics behind (no extra pass over `out`)
-                import ctypes
                 mbi = ctypes.c_int()
                 nfl = self.lib.nd_conv_winograd_stats_floats(NI, H, W, N, ctypes.byref(mbi))
                 assert nfl > 0
@@ -297,7 +293,6 @@ class UNetPlan:
         """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct
         tile shape that fits and, for 3x3 on even sizes, the Winograd variants -- best kept and cached per shape.
         ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
-        import os
         NI, H, W, C, N, ksize, _, has_rb, _, _ = key
         heur = ('direct', self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0))
         if not _autotune_enabled() or flops < 2e8:
@@ -312,7 +307,6 @@ class UNetPlan:
                 return None                           # this tile shape does not fit the problem
             if not _CLOCK_SETTLED[0]:
                 # the shader clock needs about a second of load to settle; candidates timed before that look 10 % slow
-                import time
                 t0 = time.time()
                 while time.time() - t0 < 1.0:
                     for _ in range(8):
