@@ -336,7 +336,12 @@ class UNetPlan:
                 best, best_ms = ('direct', v), ms
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
+            dma_ok = os.environ.get('ND_WINO_DMA', '0') == '1'
             for v in range(self.lib.nd_conv_winograd_num_variants()):
+                # the LDS-DMA form measures 1 % slower than its register-staged sibling once the clock has settled: it is
+                # kept (and tested) as an explicit variant but is not a tuning candidate unless asked for
+                if not dma_ok and self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16g_kernel':
+                    continue
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
