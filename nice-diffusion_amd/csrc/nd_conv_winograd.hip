@@ -566,12 +566,14 @@ __global__ void __launch_bounds__(1024, 4)
                     const f32x4 tb = d2 + sgr * d3;          // tr[cb]
                     v = ta + sgc * tb;
                 }
+                __builtin_amdgcn_s_setprio(2);          // a wave with its operands ready issues ahead of waves still loading: +1 %
 #pragma unroll
                 for (int rr = 0; rr < WNT; ++rr) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][rr][j], v[j], acc[rr], 0, 0, 0);
                 }
+                __builtin_amdgcn_s_setprio(0);
                 if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
