@@ -190,10 +190,19 @@ def main():
     # ND_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather
     # goes through host memory); the measured configuration is always nccl = RCCL, one rank per GPU
     backend = os.environ.get('ND_BENCH_BACKEND', 'nccl')
-    if backend != 'nccl':
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # ND_BENCH_STUB=1 (tests/test_distributed_gloo.py only): no GPU work at all -- the denoiser is replaced by
+    # "x + 1" on host tensors so that THIS file's N > 1 control flow (sharding, gather, barrier, MAX-reduced time, the
+    # JSON line) can be exercised with world_size 2 over gloo on a CPU-only machine.  It is never a measurement.
+    stub = os.environ.get('ND_BENCH_STUB') == '1'
+    if stub:
+        assert backend == 'gloo', 'the stub rehearsal runs over gloo only'
+        device = torch.device('cpu')
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        if backend != 'nccl':
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -203,7 +212,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    margs, model, diff = build(device)
+    if stub:
+        class _StubDiffusion:
+            use_graph = False
+
+            def denoise(self, x, kwargs, batch_size, steps_to_do, progress):
+                assert x.shape[0] == batch_size == kwargs['y'].shape[0]
+                return x + 1
+        margs, model, diff = None, None, _StubDiffusion()
+    else:
+        margs, model, diff = build(device)
     if args.no_graph:
         diff.use_graph = False
     B = args.batch
@@ -241,6 +259,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all()
+    if stub:
+        assert out.shape[0] == Bg and torch.equal(out, x_global + 1), 'gathered rows are not in global order'
+        args.no_breakdown = args.no_cpu_baseline = True
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -254,7 +275,8 @@ def main():
                                    'eta=0, cosine schedule, learned_interpolation'.format(args.chain),
                        'per_gpu_batch': B, 'global_batch': Bg, 'ddim_steps_per_pass': args.chain,
                        'parallelism': ('batch-shard x{} + all-gather'.format(world) if world > 1 else 'single GPU') +
-                                      ('' if backend == 'nccl' else ' [REHEARSAL backend={}: not a measurement]'.format(backend)),
+                                      ('' if backend == 'nccl' else ' [REHEARSAL backend={}{}: not a measurement]'.format(
+                                          backend, ', stub denoiser on CPU' if stub else '')),
                        'loop': 'hipGraph replay' if diff.use_graph else 'eager'},
             'ms_per_unet_forward_plus_update': round(ms_per_step / args.chain, 3),
         }

@@ -51,6 +51,12 @@ const char* nd_last_error(void);
 /* gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-"); "" on error. */
 const char* nd_device_arch(void);
 
+/* 64-bit digest of a list of device buffers (ptrs / nbytes are DEVICE arrays of nseg entries; sizes are multiples of 4
+ * bytes): *out = sum over words of mix(word, position in the concatenation).  Used by the host side to notice weights
+ * that were rewritten in place (p.data.copy_(), EMA swaps landing on recycled addresses) under a cached launch plan,
+ * whose repacked weight copies would otherwise go stale silently.  Reads every byte once (HBM-bound). */
+int nd_checksum_segments(const void* const* ptrs, const int64_t* nbytes, int nseg, uint64_t* out, nd_stream_t stream);
+
 /* ---- K1: sinusoidal timestep embedding (model.py:514-523): out[b] = [cos(t*f) | sin(t*f) | 0 pad] ----------
  * freqs [dim/2] is the constant fp32 table exp(arange(dim/2) * -(ln 10000)/(dim/2)) (model.py:516-517). */
 int nd_timestep_embed(const int64_t* t, const float* freqs, int B, int dim, float* out, int ld_out,
@@ -188,18 +194,19 @@ int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld,
  * noise: NHWC like x, indexed noise + t*noise_step_stride (floats) | NULL.  If NULL and noise is needed
  *   (eta != 0 / DDPM) it is drawn in-kernel from Philox4x32-10 keyed by (seed, t, first_elem + element), element =
  *   (b*HW + p)*C + c: a rank that denoises rows [r0, r1) of a larger batch passes first_elem = r0*HW*C and draws
- *   exactly the numbers a single process would have drawn for those rows.
+ *   exactly the numbers a single process would have drawn for those rows.  seed_dev | NULL: device word holding the
+ *   seed; when given it replaces `seed`, so a captured graph of the step serves every seed (the host rewrites the word).
  */
 int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step, int64_t* t_out, int B, nd_stream_t stream);
 int nd_step_advance(int32_t* step, int delta, nd_stream_t stream);
 int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, float eta,
-                 const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem,
-                 int B, int HW, int C, nd_stream_t stream);
+                 const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
+                 uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);
 int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, int var_kind,
-                 const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem,
-                 int B, int HW, int C, nd_stream_t stream);
+                 const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
+                 uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);
 /* forward diffusion q(x_t | x_0) = sqrt(abar_t) x0 + sqrt(1-abar_t) noise (diffusion.py:232-240) */
 int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,
                nd_stream_t stream);

@@ -174,15 +174,9 @@ static int launch_attn_w(const AttnArgs& a, int B, hipStream_t s) {
     constexpr int AT_NT = WAVES * 64, AT_BQ = WAVES * 32;
     auto kern = attention_kernel<HDP, WAVES>;
     const size_t lds = (size_t)2 * AT_KT * HDP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_attention_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
+    static bool attr_set[kMaxDevices] = {};
+    if (lds > 64 * 1024) {
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_attention_nhwc")) return rc;
     }
     dim3 grid((a.T + AT_BQ - 1) / AT_BQ, B * a.heads);
     hipLaunchKernelGGL(kern, grid, dim3(AT_NT), lds, s, a);

@@ -25,6 +25,22 @@ inline int check_launch(const char* fn) {
     return ND_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit to the CU's 160 KiB.  The attribute belongs to the (kernel, device) pair, so the
+// "already done" flag is kept per device ordinal; `flags` is one static array per kernel instantiation.
+constexpr int kMaxDevices = 64;
+inline int ensure_max_lds(const void* kern, bool (&flags)[kMaxDevices], const char* fn) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;   // no caching
+    if (flags[dev] && dev != kMaxDevices - 1) return ND_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+        return ND_E_LAUNCH;
+    }
+    flags[dev] = true;
+    return ND_OK;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define ND_REQUIRE(cond, fn, msg) \

@@ -653,16 +653,8 @@ static int launch_variant(const ConvArgs& a, int grid, size_t lds, hipStream_t s
         return ND_E_ARG;
     } else {
     auto kern = conv_mfma_kernel<WM, WN, TM, TN, TAPS, (OCC * WM * WN + 3) / 4>;
-    static bool attr_set = false;   // one flag per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
     return check_launch("nd_conv_nhwc");
     }

@@ -1018,16 +1018,8 @@ static constexpr int kStatsVariant = 8;        // conv_wino16_kernel: the one wh
 template <int TMW, int NSUB, bool APF, int WNT>
 static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
     auto kern = conv_wino_kernel<TMW, NSUB, APF, WNT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WNT), lds, s, a);
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
@@ -1035,16 +1027,8 @@ static int launch_wino(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
 template <int NSUB>
 static int launch_wino16(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
     auto kern = conv_wino16_kernel<NSUB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return ND_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, a);
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
@@ -1188,16 +1172,8 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
         case 9: {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16g_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) {
-                    set_error("nd_conv3x3_winograd_nhwc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                    return ND_E_LAUNCH;
-                }
-                attr_set = true;
-            }
+            static bool attr_set[kMaxDevices] = {};
+            if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino16g_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
             hipLaunchKernelGGL(conv_wino16g_kernel, dim3(grid), dim3(1024), lds, s, a);
             return check_launch(fn);
         }

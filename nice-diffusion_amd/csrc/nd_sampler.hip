@@ -63,6 +63,7 @@ struct StepArgs {
     const float* noise;
     int64_t noise_stride;
     uint64_t seed;
+    const uint64_t* seed_dev;   // if set, the Philox key is read from this device word (one captured graph, any seed)
     uint64_t idx0;     // index of this call's first element in the unpadded [B][HW][C] order of the WHOLE (unsharded) batch
     int ldx, ld_eps, HW, C;
     float w, eta;
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(256) step_elem_kernel(const StepArgs a) {
     const DdimScal k = ddim_scalars(a, t);
     const bool learned = !DDIM && a.var_kind != ND_VAR_FIXED;
     const bool need_nz = DDIM ? (k.sigma != 0.0f) : (t != 0);
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < a.total; it += (long)gridDim.x * blockDim.x) {
         const int c = (int)(it % a.C);
         const long pix = it / a.C;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) step_elem_kernel(const StepArgs a) {
         const float xt = a.x[px];
         const float e = mix_eps(a, a.eps[pe + c], a.eps_u ? a.eps_u[pe + c] : 0.f);
         float nz = 0.f;
-        if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(a.seed, t, a.idx0 + (uint64_t)it);
+        if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(seed, t, a.idx0 + (uint64_t)it);
         a.x_out[px] = DDIM ? ddim_elem(k, xt, e, nz) : ddpm_elem(a, cf, t, xt, e, learned ? a.eps[pe + a.C + c] : 0.f, nz);
     }
 }
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(256) step_pixel_kernel(const StepArgs a) {
     const DdimScal k = ddim_scalars(a, t);
     const bool learned = !DDIM && a.var_kind != ND_VAR_FIXED;
     const bool need_nz = DDIM ? (k.sigma != 0.0f) : (t != 0);
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const long npix = a.total / C;
     for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + pix * 4);
@@ -161,9 +164,9 @@ __global__ void __launch_bounds__(256) step_pixel_kernel(const StepArgs a) {
                 // the C elements of a pixel span at most two Philox pairs
                 const uint64_t it0 = a.idx0 + (uint64_t)pix * C, p0 = it0 >> 1;
                 float g[4];
-                philox_normal_pair(a.seed, t, p0, g[0], g[1]);
+                philox_normal_pair(seed, t, p0, g[0], g[1]);
                 g[2] = g[3] = 0.f;
-                if (((it0 + C - 1) >> 1) != p0) philox_normal_pair(a.seed, t, p0 + 1, g[2], g[3]);
+                if (((it0 + C - 1) >> 1) != p0) philox_normal_pair(seed, t, p0 + 1, g[2], g[3]);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const int j = (int)(it0 + c - 2 * p0);       // 0 .. 3
@@ -203,9 +206,8 @@ __global__ void step_advance_kernel(int32_t* step, int delta) {
 
 static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, int ldx, const float* eps,
                        const float* eps_u, int ld_eps, float w, const float* coef, const int32_t* step, float eta,
-                       int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, uint64_t first_elem, int B, int HW,
-                       int C,
-                       nd_stream_t stream) {
+                       int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, const uint64_t* seed_dev, uint64_t first_elem, int B,
+                       int HW, int C, nd_stream_t stream) {
     ND_REQUIRE(x && x_out && eps && coef && step, fn, "null pointer");
     ND_REQUIRE(B > 0 && HW > 0 && C > 0 && ldx >= C, fn, "bad shape");
     const int need = (!ddim && var_kind != ND_VAR_FIXED) ? 2 * C : C;
@@ -213,7 +215,7 @@ static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, 
     ND_REQUIRE(var_kind >= 0 && var_kind <= 2, fn, "bad var_kind");
     StepArgs a;
     a.x = x; a.x_out = x_out; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
-    a.noise_stride = noise_stride; a.seed = seed; a.idx0 = first_elem; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
+    a.noise_stride = noise_stride; a.seed = seed; a.seed_dev = seed_dev; a.idx0 = first_elem; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
     a.eta = eta; a.var_kind = var_kind; a.total = (long)B * HW * C;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool image_form = ldx == 4 && (ld_eps == 4 || ld_eps == 8) && C <= 4 && aligned16(x) && aligned16(x_out) &&
@@ -249,18 +251,18 @@ using namespace nd;
 
 extern "C" int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, float eta,
-                            const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem, int B,
-                            int HW, int C, nd_stream_t stream) {
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
+                            uint64_t first_elem, int B, int HW, int C, nd_stream_t stream) {
     return launch_step(true, "nd_ddim_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, eta,
-                       ND_VAR_FIXED, noise, noise_step_stride, seed, first_elem, B, HW, C, stream);
+                       ND_VAR_FIXED, noise, noise_step_stride, seed, seed_dev, first_elem, B, HW, C, stream);
 }
 
 extern "C" int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, int var_kind,
-                            const float* noise, int64_t noise_step_stride, uint64_t seed, uint64_t first_elem, int B,
-                            int HW, int C, nd_stream_t stream) {
+                            const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
+                            uint64_t first_elem, int B, int HW, int C, nd_stream_t stream) {
     return launch_step(false, "nd_ddpm_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, 0.f,
-                       var_kind, noise, noise_step_stride, seed, first_elem, B, HW, C, stream);
+                       var_kind, noise, noise_step_stride, seed, seed_dev, first_elem, B, HW, C, stream);
 }
 
 extern "C" int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,

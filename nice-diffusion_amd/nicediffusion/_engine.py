@@ -129,7 +129,11 @@ class UNetPlan:
         self.NI = NI
         dev = next(model.parameters()).device
         _hip.require_device(next(model.parameters()), 'model parameters')
-        _hip.require_gfx950(dev.index if dev.index is not None else torch.cuda.current_device())
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        _hip.require_gfx950(dev.index)
+        if torch.cuda.current_device() != dev.index:
+            raise _hip.NdHipError('build the plan with its device current (torch.cuda.device({}))'.format(dev.index))
         self.device = dev
         self.ops = []           # (fn, args, label)
         self.meta = []          # per launch: label, entry point, algorithmic flops, conv tile variant
@@ -153,6 +157,7 @@ class UNetPlan:
         self._gn_slots = 0
         self._gn_users = []     # ops needing the stats base pointer patched in
         self._cs_floats = 0     # fp32 words of partial output statistics (see conv(want_stats=True))
+        self.taps = []          # (module name, number of ops emitted when its output is complete, Act): debug hook
         _load_tune_cache()
         n_tuned = len(_TUNED)
         self._build()
@@ -440,13 +445,14 @@ class UNetPlan:
         x = Act(self.x_in, NI, R, R, self.Cin_p)
         skips = []
         # every downsampling block's output is a skip connection: it stays alive until the matching pop below
-        for block in m.downsampling:
-            x = self._run_block(block, x, None, owned=False)
+        for i, block in enumerate(m.downsampling):
+            x = self._run_block(block, x, None, owned=False, name='downsampling.{}'.format(i))
             skips.append(x)
-        x_cur = self._run_block(m.middle_block, x, None, owned=False)
-        for block in m.upsampling:
+        x_cur = self._run_block(m.middle_block, x, None, owned=False, name='middle_block')
+        for i, block in enumerate(m.upsampling):
             # torch.cat([x, xs.pop()], 1) of model.py:474 is never materialised: both sources go to the kernels
-            x_cur = self._run_block(block, x_cur, skips.pop(), owned=True, skip_owned=True)
+            x_cur = self._run_block(block, x_cur, skips.pop(), owned=True, skip_owned=True,
+                                    name='upsampling.{}'.format(i))
         # output head: GN -> SiLU -> conv3x3 (model.py:446-449)
         h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
         out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
@@ -477,12 +483,12 @@ class UNetPlan:
         self.buffers = self.pool.all      # owned for the plan's lifetime
         self.pool = None
 
-    def _run_block(self, block, x, skip, owned, skip_owned=False):
+    def _run_block(self, block, x, skip, owned, skip_owned=False, name=''):
         """Run one ``UsesStepsSequential``.  ``skip`` (if given) is concatenated after ``x`` on the channel axis."""
         from . import model as M
         cur, cur2 = x, skip
         cur_owned, cur2_owned = owned, skip_owned
-        for layer in block:
+        for j, layer in enumerate(block):
             if isinstance(layer, M.ResidualBlock):
                 nxt = self._res_block(layer, cur, cur2)
             elif isinstance(layer, M.AttentionBlock):
@@ -500,6 +506,7 @@ class UNetPlan:
                 nxt = self._upsample(layer, cur)
             else:
                 raise TypeError('unsupported layer {}'.format(type(layer)))
+            self.taps.append(('{}.{}'.format(name, j), len(self.ops), nxt))
             if cur_owned:
                 self._release(cur)
             if cur2 is not None and cur2_owned:
@@ -635,8 +642,16 @@ class UNetPlan:
         return out
 
     # ------------------------------------------------------------------------------------------------ run
+    def _require_current_device(self):
+        """Every launch goes to the CURRENT device's stream while every pointer belongs to ``self.device``: running with
+        another device current would be a GPU memory fault, not a Python error."""
+        if torch.cuda.current_device() != self.device.index:
+            raise _hip.NdHipError('plan was built for {} but cuda:{} is current; wrap the call in '
+                                  'torch.cuda.device(...)'.format(self.device, torch.cuda.current_device()))
+
     def run(self):
         """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out."""
+        self._require_current_device()
         stream = self._stream()
         self.gn_stats.zero_()
         for fn, args, label in self.ops:
@@ -644,9 +659,30 @@ class UNetPlan:
             if rc != 0:
                 raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
 
+    def run_with_taps(self):
+        """Debug hook: eager run that also returns {module name: output as NCHW tensor} for every layer of every block
+        (the names of the reference's forward hooks: ``downsampling.i.j``, ``middle_block.j``, ``upsampling.i.j``).
+        Buffers are recycled by later launches, so each output is copied out right after its last producing launch."""
+        self._require_current_device()
+        stream = self._stream()
+        self.gn_stats.zero_()
+        got, k = {}, 0
+        for idx, (fn, args, label) in enumerate(self.ops):
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
+            while k < len(self.taps) and self.taps[k][1] == idx + 1:
+                name, _, a = self.taps[k]
+                v = a.t[:a.NI * a.H * a.W * a.ld].view(a.NI, a.H, a.W, a.ld)[..., :a.C]
+                got[name] = v.permute(0, 3, 1, 2).contiguous()
+                k += 1
+        assert k == len(self.taps)
+        return got
+
     def run_timed(self):
         """Eager run with a HIP event pair around every launch (recorded on the launch stream); returns one dict per
         launch: the plan's meta (label, entry point, flops, conv variant) plus ``ms``."""
+        self._require_current_device()
         stream = self._stream()
         self.gn_stats.zero_()
         evs = []

@@ -53,8 +53,9 @@ SIGNATURES = {
     'nd_nhwc_to_nchw': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_fill_timestep': [_vp, _vp, _vp, _i, _vp],
     'nd_step_advance': [_vp, _i, _vp],
-    'nd_ddim_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _u64, _i, _i, _i, _vp],
-    'nd_ddpm_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _u64, _i, _i, _i, _vp],
+    'nd_ddim_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_ddpm_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_checksum_segments': [_vp, _vp, _i, _vp, _vp],
     'nd_qsample': [_vp, _vp, _vp, _i64, _f, _f, _vp],
     'nd_to_uint8_hwc': [_vp, _i, _vp, _i, _i, _i, _i, _vp],
 }

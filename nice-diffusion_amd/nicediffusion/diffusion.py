@@ -177,8 +177,9 @@ class Diffusion:
         out = torch.empty_like(x_0)
         a = float(np.float32(self.sqrt_alphas_cumprod[t]))
         b = float(np.float32(self.sqrt_one_minus_alphas_cumprod[t]))
-        _hip.check(_hip.load().nd_qsample(x_0.data_ptr(), noise.data_ptr(), out.data_ptr(), x_0.numel(), a, b,
-                                          torch.cuda.current_stream().cuda_stream), 'nd_qsample')
+        with torch.cuda.device(x_0.device):
+            _hip.check(_hip.load().nd_qsample(x_0.data_ptr(), noise.data_ptr(), out.data_ptr(), x_0.numel(), a, b,
+                                              torch.cuda.current_stream().cuda_stream), 'nd_qsample')
         return out
 
     # ---------------------------------------------------------------------------------------------- reverse process
@@ -209,6 +210,8 @@ class Diffusion:
             for name, p in model.named_parameters():
                 original[name] = p.data
                 p.data = ema_params[name].to(self.device)
+            model.invalidate_plans()    # plans hold repacked copies of the weights that were just swapped out
+            self._loops = {}
         try:
             if start_step is None:
                 start_step = self.rescaled_num_steps
@@ -220,11 +223,16 @@ class Diffusion:
             x = x.to(self.device)
             _hip.require_device(x, 'x')
             y = kwargs.get('y')
-            return self._run_loop(x.float().contiguous(), y, steps_to_do, progress, noise, trace, first_index)
+            if model.conditional:
+                model._check_labels(y)
+            with torch.cuda.device(x.device):       # every launch below goes to the current device's stream
+                return self._run_loop(x.float().contiguous(), y, steps_to_do, progress, noise, trace, first_index)
         finally:
             if original is not None:
                 for name, p in model.named_parameters():
                     p.data = original[name]
+                model.invalidate_plans()
+                self._loops = {}
 
     def _run_loop(self, x, y, steps_to_do, progress, noise, trace, first_index=None):
         model = self.model
@@ -243,10 +251,25 @@ class Diffusion:
         key = (id(plan), B)
         st = self._loops.get(key)
         if st is None or st['plan'] is not plan:
-            st = dict(plan=plan, coef=self.coefficient_table().to(dev).contiguous(),
-                      tmap=self.timestep_map.to(dev).contiguous(),
-                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, graph_key=None, noise=None)
+            st = dict(plan=plan, coef=None, coef_key=None, tmap=self.timestep_map.to(dev).contiguous(),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev),
+                      seed=torch.zeros(1, dtype=torch.int64, device=dev), graph=None, graph_key=None, noise=None)
             self._loops = {key: st}
+        # the coefficient rows depend on the schedule AND on the variance type ('large' / 'small' share a kernel
+        # variance kind but not column 6): refresh them whenever either changed since they were uploaded
+        coef_key = (self.sampling_var_type, self.betas.tobytes())
+        if st['coef_key'] != coef_key:
+            tab = self.coefficient_table().to(dev).contiguous()
+            if st['coef'] is not None and st['coef'].shape == tab.shape:
+                st['coef'].copy_(tab)                # same storage: a captured graph keeps working
+            else:
+                st['coef'], st['graph'] = tab, None
+            st['coef_key'] = coef_key
+            tm = self.timestep_map.to(dev).contiguous()
+            if st['tmap'].shape == tm.shape:
+                st['tmap'].copy_(tm)
+            else:
+                st['tmap'], st['graph'] = tm, None
         first = steps_to_do - 1 if first_index is None else int(first_index)
         assert 0 <= first < len(self.betas) and first - steps_to_do + 1 >= 0, 'step index out of range'
         need_noise = (not self.use_ddim) or (self.ddim_eta != 0)
@@ -267,6 +290,8 @@ class Diffusion:
         seed = self.seed
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        st['seed'].fill_(int(seed))     # the kernels read the Philox key from this device word: one graph, any seed
+        seed_ptr = st['seed'].data_ptr()
 
         # ---- stage inputs: x -> NHWC (padded to 4 channels) in the plan's input buffer; labels; step counter
         _hip.check(lib.nd_nchw_to_nhwc(x.data_ptr(), plan.x_in.data_ptr(), B, C, HW, plan.Cin_p, stream),
@@ -294,10 +319,10 @@ class Diffusion:
             plan.run()
             if self.use_ddim:
                 rc = lib.nd_ddim_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
-                                      st['step'].data_ptr(), eta, noise_ptr, noise_stride, seed, first_elem, B, HW, C, s)
+                                      st['step'].data_ptr(), eta, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             else:
                 rc = lib.nd_ddpm_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
-                                      st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, seed, first_elem, B, HW, C, s)
+                                      st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             _hip.check(rc, 'sampler step')
             if cfg:
                 plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
@@ -315,8 +340,7 @@ class Diffusion:
             import tqdm
             bar = tqdm.tqdm(total=steps_to_do)
         use_graph = self.use_graph and trace is None and steps_to_do > 1
-        gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, seed if need_noise and noise_ptr is None
-                else 0, first_elem)
+        gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, first_elem)
         done = 0
         if use_graph:
             if st['graph'] is None or st['graph_key'] != gkey:

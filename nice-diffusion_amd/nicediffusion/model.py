@@ -168,6 +168,7 @@ class DiffusionModel(nn.Module):
                                  zero_module(nn.Conv2d(first, out_channels, kernel_size=(3, 3), stride=(1, 1),
                                                        padding=(1, 1))))
         self._plans = {}
+        self.verify_weights = True     # digest the weights on the device before reusing a cached plan
 
     # -------------------------------------------------------------------------------------------- plan management
     def _residual_blocks(self):
@@ -176,25 +177,70 @@ class DiffusionModel(nn.Module):
     def _weight_signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def _weight_digest(self):
+        """64-bit digest of every parameter's bytes, computed on the device (nd_checksum_segments: one HBM pass, ~0.3 ms
+        for 1.2 GB, plus one 8-byte readback).  (data_ptr, _version) alone misses in-place rewrites through ``p.data``
+        and EMA dicts that land on recycled allocator addresses; the plan keeps private repacked copies of the conv
+        weights, so such a miss would silently mix old and new weights."""
+        params = [p for p in self.parameters()]
+        key = tuple(p.data_ptr() for p in params)
+        seg = self.__dict__.get('_digest_segments')
+        if seg is None or seg[0] != key:
+            dev = params[0].device
+            ptrs = torch.tensor([p.data_ptr() for p in params], dtype=torch.int64).to(dev)
+            sizes = torch.tensor([p.numel() * p.element_size() for p in params], dtype=torch.int64).to(dev)
+            seg = (key, ptrs, sizes, torch.zeros(1, dtype=torch.int64, device=dev))
+            self.__dict__['_digest_segments'] = seg
+        _, ptrs, sizes, out = seg
+        _hip.check(_hip.load().nd_checksum_segments(ptrs.data_ptr(), sizes.data_ptr(), len(params), out.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), 'nd_checksum_segments')
+        return int(out.item())
+
+    def invalidate_plans(self):
+        """Forget every cached launch plan (and with them the hipGraphs built on them).  Called automatically by
+        ``load_state_dict``, ``.to()`` and the EMA swap of ``Diffusion.denoise``; call it after editing weights by
+        other in-place means if ``verify_weights`` has been switched off."""
+        self._plans = {}
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_plans()
+        return super().load_state_dict(*a, **k)
+
     def _plan(self, batch):
-        """Plan for ``batch`` images on the parameters' device; rebuilt if any parameter storage/version changed."""
-        plan = self._plans.get(batch)
-        if plan is not None and plan.weight_signature != self._weight_signature():
-            plan = None
-        if plan is None:
-            for p in self.parameters():
-                if p.dtype != torch.float32:
-                    raise _hip.NdHipError('parameters must be fp32')
-            with torch.no_grad():
-                plan = UNetPlan(self, batch)
-            if len(self._plans) >= 4:
-                self._plans = {}
-            self._plans[batch] = plan
+        """Plan for ``batch`` images on the parameters' device; rebuilt if any parameter's storage, version or
+        contents changed since it was built."""
+        dev = next(self.parameters()).device
+        _hip.require_device(next(self.parameters()), 'model parameters')
+        with torch.cuda.device(dev):
+            sig = self._weight_signature()
+            digest = self._weight_digest() if self.verify_weights else None
+            plan = self._plans.get(batch)
+            if plan is not None and (plan.weight_signature != sig or plan.weight_digest != digest):
+                self.invalidate_plans()          # the other batch sizes' plans hold the same stale copies
+                plan = None
+            if plan is None:
+                for p in self.parameters():
+                    if p.dtype != torch.float32:
+                        raise _hip.NdHipError('parameters must be fp32')
+                with torch.no_grad():
+                    plan = UNetPlan(self, batch)
+                plan.weight_digest = digest
+                if len(self._plans) >= 4:
+                    self._plans = {}
+                self._plans[batch] = plan
         return plan
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
         return super()._apply(fn, *a, **k)
+
+    def _check_labels(self, y):
+        """nn.Embedding raises on an out-of-range index (model.py:459); the gather kernel must not clamp silently."""
+        if y is not None and y.numel():
+            lo, hi = int(y.min()), int(y.max())
+            if lo < 0 or hi >= self.num_classes:
+                raise IndexError('class label out of range: got [{}, {}], model has {} classes'.format(
+                    lo, hi, self.num_classes))
 
     # -------------------------------------------------------------------------------------------- forward
     @torch.no_grad()
@@ -204,20 +250,23 @@ class DiffusionModel(nn.Module):
         assert x.shape[2] == self.resolution and x.shape[3] == self.resolution, \
             'incorrect resolution: {}'.format(x.shape[2:])
         _hip.require_device(x, 'x')
+        self._check_labels(y)
         B = x.shape[0]
         plan = self._plan(B)
         lib = plan.lib
-        st = torch.cuda.current_stream().cuda_stream
-        xc = x.contiguous().float()
-        _hip.check(lib.nd_nchw_to_nhwc(xc.data_ptr(), plan.x_in.data_ptr(), B, self.in_channels,
-                                       self.resolution ** 2, plan.Cin_p, st), 'nd_nchw_to_nhwc')
-        plan.t_in.copy_(timestep.to(torch.int64))
-        if y is not None:
-            plan.y_in.copy_(y.to(torch.int64))
-        plan.run()
-        out = torch.empty(B, self.out_channels, self.resolution, self.resolution, dtype=torch.float32, device=x.device)
-        _hip.check(lib.nd_nhwc_to_nchw(plan.out.data_ptr(), out.data_ptr(), B, self.out_channels,
-                                       self.resolution ** 2, plan.Cout_p, st), 'nd_nhwc_to_nchw')
+        with torch.cuda.device(plan.device):          # launches go to the current device's stream
+            st = torch.cuda.current_stream().cuda_stream
+            xc = x.to(plan.device).contiguous().float()
+            _hip.check(lib.nd_nchw_to_nhwc(xc.data_ptr(), plan.x_in.data_ptr(), B, self.in_channels,
+                                           self.resolution ** 2, plan.Cin_p, st), 'nd_nchw_to_nhwc')
+            plan.t_in.copy_(timestep.to(torch.int64))
+            if y is not None:
+                plan.y_in.copy_(y.to(torch.int64))
+            plan.run()
+            out = torch.empty(B, self.out_channels, self.resolution, self.resolution, dtype=torch.float32,
+                              device=plan.device)
+            _hip.check(lib.nd_nhwc_to_nchw(plan.out.data_ptr(), out.data_ptr(), B, self.out_channels,
+                                           self.resolution ** 2, plan.Cout_p, st), 'nd_nhwc_to_nchw')
         return out
 
 

@@ -42,14 +42,57 @@ def to_uint8_hwc(x, invert=False):
     return u8.cpu().numpy()
 
 
+def saved_bytes(out, in_channels):
+    """uint8 image bytes exactly as the reference saves / shows them (scripts/sample.py:94-100,164,170-171).
+    Colour: trunc(v), v = clamp((x+1)*127.5, 0, 255).  One-channel models: the reference inverts in float, truncates,
+    then inverts the bytes again, 255 - trunc(255 - v) -- which is ceil(v) for non-integer v, NOT trunc(v)."""
+    if in_channels == 1:
+        return 255 - to_uint8_hwc(out, invert=True)
+    return to_uint8_hwc(out)
+
+
+def resize_linear_u8(img, width, height):
+    """cv2.resize(img, dsize=(width, height)) with its default INTER_LINEAR on uint8 HWC data, restated (OpenCV
+    imgproc resize.cpp): half-pixel centres, NO antialiasing when shrinking, 11-bit fixed-point coefficients, and the
+    exact-2x shrink special case (2x2 box average).  Used when cv2 itself is not installed."""
+    img = np.ascontiguousarray(img)
+    sh, sw = img.shape[:2]
+    if sw == 2 * width and sh == 2 * height:          # INTER_LINEAR -> INTER_AREA fast path
+        a = img.astype(np.int32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+    def taps(dst, src):
+        scale = src / dst
+        f = (np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        frac = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        i0[lo], frac[lo] = 0, 0.0
+        hi = i0 >= src - 1
+        i0[hi], frac[hi] = src - 1, 0.0
+        i1 = np.minimum(i0 + 1, src - 1)
+        w1 = np.rint(frac * 2048.0).astype(np.int32)
+        w0 = np.rint((1.0 - frac) * 2048.0).astype(np.int32)
+        return i0, i1, w0, w1
+    x0, x1, a0, a1 = taps(width, sw)
+    y0, y1, b0, b1 = taps(height, sh)
+    src = img.astype(np.int32)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]          # horizontal pass, x2048
+    r0, r1 = rows[y0], rows[y1]
+    out = ((((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def load_start_image(path, resolution):
+    """scripts/sample.py:55-58: imread (BGR) -> resize (INTER_LINEAR) -> /127.5 - 1 in float64 -> RGB, CHW, fp32."""
     try:
-        from PIL import Image
-        img = np.asarray(Image.open(path).convert('RGB').resize((resolution, resolution), Image.BILINEAR))
-    except ImportError:
         from cv2 import imread, resize
         img = resize(imread(path), dsize=(resolution, resolution))[..., ::-1]
-    return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float() / 127.5 - 1
+    except ImportError:
+        from PIL import Image
+        img = resize_linear_u8(np.asarray(Image.open(path).convert('RGB')), resolution, resolution)
+    arr = np.ascontiguousarray(img).astype(np.float64) / 127.5 - 1
+    return torch.from_numpy(arr).permute(2, 0, 1).float()
 
 
 def main(argv=None):
@@ -103,8 +146,7 @@ def main(argv=None):
         if wordy:
             print('Denoising sample {}! :)'.format(i + 1))
         out = diffusion.denoise(x=data, kwargs={'y': labels}, batch_size=B, progress=wordy, steps_to_do=steps)
-        # grayscale models are displayed/saved inverted-then-reinverted by the reference; net effect: identity
-        results.append((to_uint8_hwc(out), None if labels is None else labels.cpu().numpy()))
+        results.append((saved_bytes(out, C), None if labels is None else labels.cpu().numpy()))
     torch.cuda.synchronize()
     if wordy:
         dt = time.time() - t0

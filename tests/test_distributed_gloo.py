@@ -79,3 +79,28 @@ def test_sharded_denoise_matches_single_process(n):
     from nicediffusion.parallel import shard_slice
     exp = np.concatenate([np.full((shard_slice(n, r, 2).stop - shard_slice(n, r, 2).start, 2), float(r)) for r in (0, 1)])
     assert np.array_equal(g, exp)
+
+
+def test_bench_multi_rank_branch_over_gloo():
+    """bench.py's own N > 1 branch (shard_slice of the global batch, one_pass + all_gather_rows, barrier, MAX-reduced
+    time, rank 0's JSON line) with world_size 2 over gloo and the denoiser stubbed out (ND_BENCH_STUB=1: no GPU work)."""
+    import json
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE='2', RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), ND_BENCH_BACKEND='gloo', ND_BENCH_STUB='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+                                       '--warmup', '1', '--batch', '5'], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert not [l for l in outs[1][0].splitlines() if l.startswith('{')], 'only rank 0 prints the JSON line'
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 10 and rec['config']['per_gpu_batch'] == 5
+    assert 'REHEARSAL' in rec['config']['parallelism'] and rec['vs_baseline'] is None
+    assert abs(rec['value'] - 10 * 3 / (rec['ms_per_step'] * 3e-3)) / rec['value'] < 0.02      # whole-job images / MAX time

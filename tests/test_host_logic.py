@@ -230,3 +230,32 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and 'multiple of 8' in _hip.last_error()
     rc = lib.nd_groupnorm_stats_nhwc(16, 30, 32, None, 0, 0, None, 0, 16, 1, 4, 32, None)
     assert rc == -1
+
+
+def test_start_image_resize_follows_cv2_linear_semantics(tmp_path):
+    """scripts/sample.py --start_img: cv2.resize's default INTER_LINEAR (half-pixel centres, no antialiasing, exact-2x box
+    case), restated for hosts without cv2; checked against torch's non-antialiased bilinear kernel (same sampling
+    positions, float arithmetic) to within the fixed-point rounding."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'nice-diffusion_amd', 'scripts'))
+    import sample
+    rng = np.random.default_rng(0)
+    for (h, w, r) in ((40, 56, 16), (9, 13, 16), (16, 16, 16), (100, 37, 28)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = sample.resize_linear_u8(img, r, r)
+        assert got.shape == (r, r, 3) and got.dtype == np.uint8
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(r, r),
+                                              mode='bilinear', align_corners=False, antialias=False)[0]
+        assert np.abs(got.astype(float) - ref.permute(1, 2, 0).numpy()).max() <= 1.0
+        if (h, w) == (r, r):
+            assert np.array_equal(got, img)
+    img = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    box = (img.reshape(16, 2, 16, 2, 3).astype(int).sum((1, 3)) + 2) >> 2
+    assert np.array_equal(sample.resize_linear_u8(img, 16, 16), box.astype(np.uint8))
+    assert (sample.resize_linear_u8(np.full((31, 17, 3), 77, np.uint8), 16, 16) == 77).all()
+    from PIL import Image
+    p = str(tmp_path / 'start.png')
+    Image.fromarray(img).save(p)
+    t = sample.load_start_image(p, 16)
+    assert t.shape == (3, 16, 16) and t.dtype == torch.float32
+    assert torch.equal(t, torch.from_numpy(box.astype(np.float64) / 127.5 - 1).permute(2, 0, 1).float())

@@ -142,3 +142,33 @@ def test_config1_end_to_end(golden_dir):
     assert np.abs(out.numpy() - g['out']).max() < 1e-3
     u8 = ((out + 1) * 127.5).clamp(0, 255).to(torch.uint8).numpy()
     assert (np.abs(u8.astype(int) - g['u8'].astype(int)) <= 1).all()
+
+
+def test_diffuse_and_img2img_chain(golden_dir):
+    """N3 entry pinned by the reference: Diffusion.diffuse for steps 1/4/10/None/99 and diffuse -> denoise(steps_to_do=k)
+    chains (diffusion.py:133-153,192-197,232-240; sample.py:54-64,76-78)."""
+    g = _load(golden_dir, 'diffuse_img2img.npz')
+    cfg = TINY_CFGS['adagn_updown']
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    x0, nz, y = torch.from_numpy(g['x0']), torch.from_numpy(g['nz']), torch.from_numpy(g['y'])
+    noises = torch.from_numpy(g['noises'])
+    for use_ddim in (True, False):
+        kw = dict(use_ddim=True, ddim_eta=0.0) if use_ddim else dict(use_ddim=False)
+        so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, 10, 'cosine'),
+                              'learned_interpolation', **kw)
+        for steps in (1, 4, 10, None, 99):
+            assert np.abs(so.diffuse(x0, steps, nz).numpy() - g['diffuse/{}'.format(steps)]).max() == 0
+        for k in (1, 4, 10):
+            out = so.denoise(so.diffuse(x0, k, nz), y, steps_to_do=k, noises=list(noises))
+            assert np.abs(out.numpy() - g['chain/{}/{}'.format('ddim' if use_ddim else 'ddpm', k)]).max() < 1e-5
+
+
+def test_saved_bytes_of_one_channel_model(golden_dir):
+    """The bytes the reference writes for a 1-channel model are 255 - uint8(255 - v) = ceil(v), one level above the plain
+    truncation for every non-integer v (sample.py:98-100,164,170-171)."""
+    g = _load(golden_dir, 'config1_emnist_ddim50.npz')
+    v = ((torch.from_numpy(g['out']) + 1) * 127.5).clamp(0, 255)
+    saved = 255 - (255 - v).to(torch.uint8).numpy()[:, 0]
+    assert np.array_equal(saved, g['u8_saved'])
+    nonint = (v != v.round()).numpy()[:, 0]
+    assert np.array_equal(saved[nonint].astype(int), g['u8'][:, 0][nonint].astype(int) + 1)

@@ -261,7 +261,58 @@ def gen_config1():
     print('   config1 oracle-vs-reference', err, 'absmax', out.abs().max().item())
     assert err < 1e-3
     u8 = ((out + 1) * 127.5).clamp(0, 255).to(torch.uint8)              # sample.py:94 + :164
-    save('config1_emnist_ddim50.npz', xT=xT.numpy(), y=y.numpy(), out=out.numpy(), u8=u8.numpy())
+    # what the reference WRITES for a 1-channel model: the same tensor expressions as sample.py:94,98-100 (float
+    # inversion, stacked to 3 channels), :164 (uint8 truncation, HWC) and :170-171 (second inversion, channel 0)
+    o = ((out + 1) * 127.5).clamp(0, 255).cpu()
+    o3 = torch.stack((255 - o.squeeze(),) * 3, dim=1)
+    saved = o3.to(torch.uint8).permute(0, 2, 3, 1).detach().numpy()
+    saved = 255 - saved[..., 0]
+    save('config1_emnist_ddim50.npz', xT=xT.numpy(), y=y.numpy(), out=out.numpy(), u8=u8.numpy(), u8_saved=saved)
+
+
+# ------------------------------------------------------------------------------------------------ N3: diffuse / img2img
+def gen_diffuse():
+    """Reference Diffusion.diffuse (diffusion.py:133-153,232-240) and the --start_img chain of sample.py:54-64,76-78:
+    diffuse(x_0, k) -> denoise(steps_to_do=k), DDIM eta=0 and DDPM, with the reverse-step noise captured."""
+    cfg = dict(TINY_CFGS['adagn_updown'])
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    torch.manual_seed(3)
+    x0, nz = torch.randn(2, 3, 16, 16).clamp(-1, 1), torch.randn(2, 3, 16, 16)
+    y = torch.tensor([1, 7])
+    arrs = dict(x0=x0.numpy(), nz=nz.numpy(), y=y.numpy())
+    d = Diffusion(m, 1000, 10, 'learned_interpolation', 'hybrid', beta_schedule='cosine', device=torch.device('cpu'))
+    for steps in (1, 4, 10, None, 99):
+        arrs['diffuse/{}'.format(steps)] = d.diffuse(x0, steps_to_do=steps, noise=nz).numpy()
+    torch.manual_seed(5)
+    noises = torch.randn(10, 2, 3, 16, 16)
+    arrs['noises'] = noises.numpy()
+    orig = torch.randn_like
+    for use_ddim in (True, False):
+        kw = dict(use_ddim=True, ddim_eta=0.0) if use_ddim else dict(use_ddim=False)
+        d = Diffusion(m, 1000, 10, 'learned_interpolation', 'hybrid', beta_schedule='cosine',
+                      device=torch.device('cpu'), **kw)
+        so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, 10, 'cosine'),
+                              'learned_interpolation', **kw)
+        for k in (1, 4, 10):
+            it = {'i': k - 1}
+
+            def fake_randn_like(z, *a, **kk):
+                n = noises[it['i']]
+                it['i'] -= 1
+                return n.clone()
+            torch.randn_like = fake_randn_like
+            try:
+                xk = d.diffuse(x_0=x0, steps_to_do=k, noise=nz)
+                out = d.denoise(x=xk, kwargs={'y': y}, batch_size=2, progress=False, steps_to_do=k)
+            finally:
+                torch.randn_like = orig
+            ref = so.denoise(so.diffuse(x0, k, nz), y, steps_to_do=k, noises=list(noises))
+            err = (ref - out).abs().max().item()
+            print('   img2img', 'ddim' if use_ddim else 'ddpm', k, 'oracle-vs-reference', err)
+            assert err < 1e-4
+            arrs['chain/{}/{}'.format('ddim' if use_ddim else 'ddpm', k)] = out.numpy()
+    save('diffuse_img2img.npz', **arrs)
 
 
 # ------------------------------------------------------------------------------------------------ CLI dicts (A12)
@@ -286,8 +337,8 @@ def gen_embed():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets']
-    fns = dict(schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
+    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse']
+    fns = dict(diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
                samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets)
     for w in which:
         print('==', w)
