@@ -394,6 +394,47 @@ def test_full_size_properties_config2():
     assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5
 
 
+def test_config4_workload_fp32_ddpm_cfg_128():
+    """BASELINE configs[3]'s workload in fp32: 128x128 preset with num_classes=1001 (CFG adds the null class,
+    utils.py:211-212), 1000-step DDPM (use_ddim=False, linear schedule), classifier-free guidance w=0.8 -> 2B forwards
+    per step (diffusion.py:242-316, :278-284).  Teacher-forced steps at B=1 against the oracle with injected noise at
+    both ends of the chain, then graph replay vs eager and run-to-run determinism at B=8 (16 forwards per step)."""
+    margs = dict(DA.OPENAI_128_MODEL_ARGS)
+    margs['num_classes'] = 1001
+    m = build(margs)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    kw = dict(beta_schedule='linear', use_ddim=False, guidance_method='classifier_free', guidance_strength=0.8)
+    d = Diffusion(m, 1000, 1000, 'learned_interpolation', 'hybrid', device=DEV, **kw)
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, margs, xx, tt, yy), DO.Schedule(1000, 1000, 'linear'),
+                          'learned_interpolation', use_ddim=False, guidance_method='classifier_free', guidance_strength=0.8)
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 128, 128)
+    y = torch.tensor([417])
+    for t in (999, 0):
+        nz = torch.randn(1, 3, 128, 128)
+        noises = torch.zeros(t + 1, 1, 3, 128, 128)
+        noises[t] = nz
+        got = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=1, steps_to_do=1, first_index=t, progress=False,
+                        noise=noises).cpu()
+        ref, _ = so.ddpm_step(x, t, y, nz)
+        err = (got - ref).abs().max().item()
+        assert err < 1e-3, (t, err)
+        del noises
+    B = 8
+    xb = torch.randn(B, 3, 128, 128)
+    yb = (torch.arange(B) * 37) % 1000 + 1
+    d.seed = 123
+    a = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    b = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    d.use_graph = False
+    c = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5 and (a - c).abs().max().item() < 1e-5
+    # row 0 of the batched run = the same row run alone (nothing on the path mixes samples; Philox is keyed per element)
+    d.use_graph = True
+    solo = d.denoise(x=xb[:1], kwargs={'y': yb[:1].to(DEV)}, batch_size=1, steps_to_do=3, progress=False)
+    assert (solo - a[:1]).abs().max().item() < 1e-4
+
+
 def test_sample_cli_end_to_end(tmp_path, golden_dir):
     """scripts/sample.py with --custom flags on a tiny checkpoint: images come out as JPGs named like the reference's
     ({label}_sample{n}.jpg), --cpu is refused, and the uint8 conversion matches the oracle's loop output."""
