@@ -34,6 +34,11 @@ typedef void* nd_stream_t; /* hipStream_t */
 #define ND_CONV_RES_UP2X 2  /* residual is stored at half resolution and read through nearest-2x upsampling */
 #define ND_CONV_SILU_OUT 4  /* apply SiLU to the result (after bias; residual must be NULL) */
 #define ND_CONV_GN_SILU 8   /* with gnA/gnB: SiLU after the fused GroupNorm affine of the INPUT */
+#define ND_CONV_OUT_F32 16  /* nd_conv_bf16_nhwc only: write the fp32 accumulators (out is float*) instead of bf16 */
+
+/* element type of activation tensors where an entry point takes `dtype` (weights/bias/statistics keep their own types) */
+#define ND_DT_F32 0
+#define ND_DT_BF16 1
 
 /* flags for nd_groupnorm_apply_nhwc */
 #define ND_GN_SILU 1        /* SiLU after the affine */
@@ -122,6 +127,27 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
                              int NI, int H, int W, int N, int flags, int variant,
                              const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream);
 
+/* ---- bf16 path (BASELINE configs[3], [4]): bf16 activations and weights in HBM, fp32 accumulation -------------------
+ * nd_conv_bf16_nhwc: the same convolution and fused options as nd_conv_nhwc (ksize 1 | 3; two-source input, bias,
+ *   rowbias, residual, ND_CONV_IN_UP2X / RES_UP2X / SILU_OUT) on v_mfma_f32_32x32x16_bf16.  x0 / x1 / residual / out
+ *   are bf16 NHWC (channel counts and strides multiples of 8 = 16 bytes); bias and rowbias stay fp32; with
+ *   ND_CONV_OUT_F32 `out` is float* and receives the fp32 accumulators (the UNet's last conv, feeding the fp32 sampler
+ *   update).  `w` comes from nd_repack_conv_weight_bf16 (fp32 OIHW -> bf16 fragment order
+ *   [c64][n tile][tap][k-step][lane][8], nd_conv_bf16_weight_elems elements).  `variant` < 0: cost model.
+ * nd_f32_to_bf16_rows: [rows][ldx] fp32 -> [rows][ldo] bf16, channels [C, ldo) zeroed (x_t enters the bf16 UNet).
+ * nd_attention_bf16_nhwc: nd_attention_nhwc on bf16 q/k/v (both products on bf16 MFMA, softmax in fp32), bf16 out. */
+int nd_conv_bf16_num_variants(void);
+int nd_conv_bf16_variant_info(int variant, int* bm, int* bn, int* threads);
+int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize);
+int nd_repack_conv_weight_bf16(const float* w_oihw, void* w_out, int N, int C, int ksize, nd_stream_t stream);
+int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, int C, int64_t rows, nd_stream_t stream);
+int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                      const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                      const void* residual, int ldr, void* out, int ldo,
+                      int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream);
+int nd_attention_bf16_nhwc(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int T, int heads, int hd,
+                           int q_off, int k_off, int v_off, int head_stride, float scale, nd_stream_t stream);
+
 /* Direct (non-MFMA) convolution for the shapes the MFMA path does not take: 3x3 stride 2 pad 1
  * (Downsample with_conv, model.py:103-105).  Weights in PyTorch's own OIHW layout.  out is [NI, Ho, Wo, N]. */
 int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, const float* bias,
@@ -134,20 +160,24 @@ int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, con
 int64_t nd_conv_weight_floats(int N, int C, int ksize);
 int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, nd_stream_t stream);
 
-/* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1) ------------------------------------------
- * stats: accumulates per (img, group) sum and sum of squares of (x + addvec[img,c]) in float64 into
- *   stats[NI][G][2]; the caller zeroes `stats` beforehand (hipMemsetAsync).  addvec [NI][ld_add] | NULL is the
+/* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1); activations fp32 or bf16 (`dtype`) ---------
+ * stats: per (img, group) sum and sum of squares of (x + addvec[img,c]) in float64 -> stats[NI][G][2], WRITTEN (not
+ *   accumulated) and bitwise reproducible: fixed-order tree inside a block, per-block partials in `workspace`, the
+ *   last block of an image (ticket) adds them in block order -- no floating-point atomics.  `workspace` holds
+ *   nd_groupnorm_stats_workspace_bytes(...) bytes, 256-byte aligned, its first NI int32 (the tickets) ZERO on entry
+ *   (they are left zero), and may be shared by launches that are stream-ordered.  addvec [NI][ld_add] | NULL is the
  *   non-adaptive timestep-embedding add that precedes out_norm (model.py:205).
  * apply: y = ((x+addvec) - mean) * rstd * gamma + beta;  if scale: y = y*(1+scale[img,c]) + shift[img,c]
  *   (model.py:201-203); optional SiLU (model.py:190,207,447); optional 2x2 average pool of the result
- *   (model.py:111 applied to h, :192).  eps as nn.GroupNorm (1e-5).
+ *   (model.py:111 applied to h, :192).  eps as nn.GroupNorm (1e-5).  out has the input's element type.
  */
-int nd_groupnorm_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                            const float* addvec, int ld_add, double* stats, int NI, int HW, int G,
-                            nd_stream_t stream);
+int64_t nd_groupnorm_stats_workspace_bytes(int NI, int HW, int C, int G, int dtype);
+int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                            const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW, int G,
+                            int dtype, nd_stream_t stream);
 /* Partial output statistics written by nd_conv3x3_winograd_stats_nhwc (p0: rows0 = mbi*4 partial rows per image over C0
- * channels; optionally concatenated with p1 over C1 channels) -> ADDS the per-group sums to stats [NI][G][2], the
- * array nd_groupnorm_stats_nhwc fills (caller zeroes it, as for that function). */
+ * channels; optionally concatenated with p1 over C1 channels) -> WRITES the per-group sums to stats [NI][G][2] (the
+ * array nd_groupnorm_stats_nhwc fills), summed in a fixed order. */
 int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
                                      double* stats, int NI, int G, nd_stream_t stream);
 /* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions
@@ -155,11 +185,11 @@ int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const f
 int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
                         const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
                         int NI, int C, int HW, int G, float eps, nd_stream_t stream);
-int nd_groupnorm_apply_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, const double* stats,
                             const float* gamma, const float* beta,
                             const float* scale, const float* shift, int ld_ss,
-                            float* out, int ldo, int NI, int H, int W, int G, float eps, int flags,
+                            void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,
                             nd_stream_t stream);
 
 /* ---- K7: attention core softmax(q k^T * scale) v over T tokens (model.py:266-287) ---------------------------
@@ -178,7 +208,9 @@ int nd_upsample2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int
  * weights w'[n][(p,q,c)][u][v] = w[n][c][dy][dx], (dy -> p,u): 0 -> (1,0), 1 -> (0,1), 2 -> (1,1) (same for dx -> q,v), zero
  * elsewhere -- i.e. it runs on nd_conv_nhwc / nd_conv3x3_winograd_nhwc. */
 int nd_space_to_depth2_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
-int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C, nd_stream_t stream);
+/* 2x2 average pool; fp32 or bf16 elements (`dtype`).  nd_upsample2x_nhwc / nd_space_to_depth2_nhwc only move 16-byte
+ * groups of channels, so bf16 tensors go through them as fp32 tensors of C/2 channels and ld/2 strides. */
+int nd_avgpool2x_nhwc(const void* x, int ldx, void* out, int ldo, int NI, int H, int W, int C, int dtype, nd_stream_t stream);
 
 /* ---- layout at the API edge: NCHW [NI][C][HW] <-> NHWC [NI][HW][ld] (pad channels written as 0) ------------- */
 int nd_nchw_to_nhwc(const float* src, float* dst, int NI, int C, int HW, int ld, nd_stream_t stream);

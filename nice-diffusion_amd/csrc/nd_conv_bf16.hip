@@ -1,0 +1,624 @@
+// bf16 form of K5/K6 (BASELINE configs[3], [4]): 3x3 (stride 1, pad 1) and 1x1 convolution / linear as an implicit
+// GEMM on v_mfma_f32_32x32x16_bf16 -- bf16 activations and weights in HBM, fp32 accumulation, bf16 (or fp32) output.
+//
+// Same fused surroundings as the fp32 kernel (nd_conv_mfma.hip): two-source input = torch.cat of the skip connection
+// (model.py:474), bias, per-image timestep-embedding add (model.py:205), residual add (model.py:211,291), nearest-2x
+// upsampling of the input or of the residual (model.py:77-79), SiLU on the output.
+//
+// The bf16 matrix instruction does 16x the flops per cycle of the fp32 one, so the kernel is shaped by operand delivery,
+// not by the matrix pipe:
+//   wave tile   TM x TN tiles of 32x32 with TM*TN = 8 for the large layers (128 px x 64 ch: 8 MFMAs = 256 cycles per
+//               k-step against 4 ds_read_b128 + 2 global_load_dwordx4), 8 waves = 2 per SIMD, 256 px x 256 ch per block:
+//               a block re-reads its weight slab once per 256 pixels (the dominant L2 -> CU stream at this rate).
+//   A operand   activations: the (TH+2)x(TW+2) halo tile of a 64-channel chunk (128-byte rows = full cache lines per
+//               pixel) is staged in LDS once and read at 9 shifted positions; lane (pixel i, half h) reads ONE 16-byte
+//               slot = 8 channels = its whole B-side fragment of a k-step (k = 16 channels).  XOR swizzle as in the
+//               fp32 kernel (rows are 128 bytes in both).
+//   B operand   weights, pre-packed into fragment order [c64][n tile][tap][k-step][lane][8 bf16]: one coalesced 1 KiB
+//               global_load_dwordx4 per fragment, straight to VGPRs, three k-steps ahead (ring of 4).
+//   D^T = W.X^T a lane ends up with ONE pixel and 4 consecutive output channels per register group: 8-byte bf16 stores.
+#include "nd_conv_common.h"
+
+namespace nd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsH {
+    const __bf16* x0;
+    const __bf16* x1;
+    const __bf16* w;      // packed fragments
+    const float* bias;
+    const float* rowbias;
+    const __bf16* res;
+    void* out;            // bf16, or fp32 when out_f32
+    int C0, C1, ldx0, ldx1;
+    int NI, H, W;         // output (= virtual input) size
+    int Hs, Ws;           // stored input size (H >> up)
+    int up, res_up;
+    int N, ldo, ldr, ld_rowbias;
+    int NT32, NC64;
+    int thl, twl, nibl;
+    int tiles_x, tiles_y, mt, nt, ngroup;
+    int silu_out, out_f32;
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
+    union { f32x4 f; bf16x8 h; } u;
+    u.f = v;
+    return u.h;
+}
+
+template <int WM, int WN, int TM, int TN, int TAPS>
+__global__ void __launch_bounds__(WM* WN * 64, 2)
+    conv_bf16_kernel(const ConvArgsH p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int NSUB = (TAPS == 9) ? 1 : 2;          // 64-channel sub-chunks per LDS chunk
+    constexpr int SPR = 8 * NSUB;                      // 16-byte slots per halo pixel row
+    constexpr int ROWF = 32 * NSUB;                    // 4-byte words per halo pixel row
+    constexpr int KSTEPS = 4 * NSUB;                   // k-steps (16 channels each) per chunk and tap
+    constexpr int STEPS = TAPS * 4;                    // fragments per 64-channel chunk and n tile
+    // halo 16-byte items per thread per chunk: 3x3 tiles carry up to 1.5625x their pixels as halo (8x8 maps; fetched in 3 batches,
+    // one per tap row); the 1x1 form has exactly BM rows (fetched one group per k-step)
+    constexpr int NBI = (TAPS == 9) ? (((BM * 25 + 2 * NT - 1) / (2 * NT) + 2) / 3) : ((BM * SPR / NT + KSTEPS - 1) / KSTEPS);
+    constexpr int NBATCH = (TAPS == 9) ? 3 : KSTEPS;
+    constexpr int MAXHI = NBI * NBATCH;
+    static_assert(NT % SPR == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][ROWF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    // ---- XCD-aware block -> tile map (see nd_conv_mfma.hip)
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2 * PAD, HW = TW + 2 * PAD;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    // ---- halo descriptors
+    const int hslot = tid % SPR;
+    const int hrow0 = tid / SPR;
+    int gpix[MAXHI];
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) {
+        const int hp = hrow0 + k * (NT / SPR);
+        int g = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - PAD + hy, ix = ox0 - PAD + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpix[k] = g;
+    }
+
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = (p.NC64 + NSUB - 1) / NSUB;
+
+    auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int c = ch * (64 * NSUB) + (hslot << 3);
+        if (g >= 0 && c < Ctot) {
+            const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        return v;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v) {
+        const int hp = hrow0 + k * (NT / SPR);
+        if (hp < HP) {
+            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    };
+
+    // ---- per-lane operand rows
+    int a_hp[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 32 + l31;
+        const int li = m >> (p.thl + p.twl);
+        const int py = (m >> p.twl) & (TH - 1);
+        const int px = m & (TW - 1);
+        a_hp[mi] = li * HPI + py * HW + px;
+    }
+    // weight fragment stream of n tile ni: [c64][n tile][step][lane][8 bf16]; one fragment = 512 bf16 = 1 KiB
+    const __bf16* bp[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        int ntile = nblk * (BN / 32) + wn * TN + ni;
+        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;      // N tail: results are discarded in the epilogue
+        bp[ni] = p.w + (size_t)ntile * (STEPS * 512) + lane * 8;
+    }
+    const size_t c64_jump = (size_t)(p.NT32 - 1) * (STEPS * 512);
+    int ld_in_c64 = 0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // operand registers.  Weights: ring of RING fragments per n tile, fetched RING-1 k-steps ahead.  Activations: ONE
+    // register set -- the slot of tile mi for the NEXT k-step is re-read right behind the MFMAs that consumed it and has
+    // the other TM-1 tiles' MFMAs (>= 190 cycles) to land; 128 accumulator + 16 + 24 operand registers leave room for
+    // two waves per SIMD.
+    constexpr int RING = (TAPS == 9) ? 3 : 4;
+    constexpr int BDIST = RING - 1;
+    f32x4 a_fr[TM], b_fr[RING][TN];
+    // the packed buffer carries a whole zero chunk at the end, so the stream may always run ahead
+    auto advance_b = [&](f32x4 (&dst)[TN]) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+            bp[ni] += 512;
+        }
+        if (++ld_in_c64 == STEPS) {
+            ld_in_c64 = 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bp[ni] += c64_jump;
+        }
+    };
+    // one k-step: TM x TN MFMAs; behind tile mi's MFMAs its fragment for the next step is read from LDS word offset
+    // noff[mi] (already swizzled)
+    auto mfma_step = [&](const f32x4 (&bw)[TN], const float* hbuf, const int (&noff)[TM]) {
+        ND_PRIO(1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bw[ni]), as_bf16x8(a_fr[mi]), acc[mi][ni], 0, 0, 0);
+            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + noff[mi]);
+        }
+        ND_PRIO(0);
+    };
+
+    // ---- prologue: chunk 0 halo, first weight fragments
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
+#pragma unroll
+    for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int hp = a_hp[mi];
+            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
+        }
+        if constexpr (TAPS == 9) {
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                // next chunk's halo arrives in 3 batches of NBI items (one batch per tap row), fetched at the top of the
+                // row and parked in the other LDS buffer after its 12 k-steps (~3000 cycles later)
+                int gs[NBI];
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) {
+                    int g = gpix[i];
+                    g = (dy == 1) ? gpix[NBI + i] : g;
+                    g = (dy == 2) ? gpix[2 * NBI + i] : g;
+                    gs[i] = halo_next ? g : -1;
+                }
+                f32x4 phb[NBI];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tapoff = dy * HW + dx;
+                    const int tapoff_n = (dx < 2) ? tapoff + 1 : ((dy < 2) ? (dy + 1) * HW : 0);
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const int st = dx * 4 + kc;                 // 0 .. 11, compile-time: ring slots are static
+                        advance_b(b_fr[(st + BDIST) % RING]);
+                        if (dx == 0 && kc == 0) {
+#pragma unroll
+                            for (int i = 0; i < NBI; ++i) phb[i] = load_halo_pixel(gs[i], ch + 1);
+                        }
+                        int noff[TM];
+                        {
+                            const int nslot = (((kc + 1) & 3) << 1) | lh;
+                            const int toff = (kc == 3) ? tapoff_n : tapoff;
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi) {
+                                const int hp = a_hp[mi] + toff;     // (after the last step of a chunk this reads stale but
+                                noff[mi] = hp * ROWF + ((nslot ^ swz(hp)) << 2);   //  in-bounds data that is discarded)
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(b_fr[st % RING], hbuf, noff);
+                    }
+                }
+                if (halo_next) {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) {
+                        const int k = dy * NBI + i;      // dy is a run-time value: the item index is plain arithmetic
+                        const int hp = hrow0 + k * (NT / SPR);
+                        if (hp < HP) {
+                            float* dst = smem + ((ch + 1) & 1) * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+                            *reinterpret_cast<f32x4*>(dst) = phb[i];
+                        }
+                    }
+                }
+            }
+        } else {
+            // 1x1: KSTEPS k-steps per chunk; the next chunk's rows are fetched one group of NBI per step and parked two
+            // steps later (the last two groups behind the loop)
+            f32x4 ph[KSTEPS][NBI];
+            const bool second = (ch * NSUB + 1) < p.NC64;          // the chunk's second 64-channel half holds real channels
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks < 4 || second) {
+                    advance_b(b_fr[(ks + BDIST) % RING]);
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) ph[ks][i] = load_halo_pixel(halo_next ? gpix[ks * NBI + i] : -1, ch + 1);
+                    int noff[TM];
+                    {
+                        const int nstep = (ks + 1) & (KSTEPS - 1);      // wraps to 0 after the last step: discarded
+                        const int nslot = (nstep << 1) | lh;
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) noff[mi] = a_hp[mi] * ROWF + ((nslot ^ swz(a_hp[mi])) << 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(b_fr[ks % RING], hbuf, noff);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) ph[ks][i] = load_halo_pixel(halo_next ? gpix[ks * NBI + i] : -1, ch + 1);
+                }
+                if (ks >= 2 && halo_next) {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - 2) * NBI + i, (ch + 1) & 1, ph[ks - 2][i]);
+                }
+            }
+            if (halo_next) {
+#pragma unroll
+                for (int ks = KSTEPS - 2; ks < KSTEPS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) store_halo_item(ks * NBI + i, (ch + 1) & 1, ph[ks][i]);
+            }
+        }
+        // halo hand-over: only LDS traffic has to be complete; the weight prefetch stays in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 32 + l31;
+        const int li = m >> (p.thl + p.twl);
+        const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+        const int ox = ox0 + (m & (TW - 1));
+        const int img = img0 + li;
+        if (img < p.NI && oy < p.H && ox < p.W) {
+            const size_t opix = (size_t)(img * p.H + oy) * p.W + ox;
+            const float* rb = p.rowbias ? p.rowbias + (size_t)img * p.ld_rowbias : nullptr;
+            const __bf16* rr = nullptr;
+            if (p.res) {
+                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
+                rr = p.res + rp * p.ldr;
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                    if (n + 3 < p.N && vec_ok) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+                        if (rr) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        if (p.out_f32) {
+                            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + opix * p.ldo + n) = v;
+                        } else {
+                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = acc[mi][ni][4 * g4 + e];
+                                if (p.bias) v += p.bias[n + e];
+                                if (rb) v += rb[n + e];
+                                if (rr) v += (float)rr[n + e];
+                                if (p.silu_out) v = fast_silu(v);
+                                if (p.out_f32) static_cast<float*>(p.out)[opix * p.ldo + n + e] = v;
+                                else static_cast<__bf16*>(p.out)[opix * p.ldo + n + e] = (__bf16)v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fp32 OIHW [N][C][k][k] (also Conv1d [N][C][1], Linear [N][C]) -> bf16 fragment order
+//   out[((((c64*NT32 + ntile)*taps + tap)*4 + ks)*64 + lane)*8 + j] = bf16(w[n = ntile*32 + (lane&31)][c = c64*64 + ks*16 + (lane>>5)*8 + j][tap])
+// zero for n >= N, c >= C and for the padding chunks.
+__global__ void pack_conv_weight_bf16_kernel(const float* w, __bf16* out, int N, int C, int taps, int NT32, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(it & 7);
+        const int lane = (int)((it >> 3) & 63);
+        long r = it >> 9;
+        const int ks = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % taps);
+        r /= taps;
+        const int ntile = (int)(r % NT32);
+        const int c64 = (int)(r / NT32);
+        const int n = ntile * 32 + (lane & 31);
+        const int c = c64 * 64 + ks * 16 + (lane >> 5) * 8 + j;
+        out[it] = (__bf16)((n < N && c < C) ? w[((size_t)n * C + c) * taps + tap] : 0.f);
+    }
+}
+
+__global__ void f32_to_bf16_rows_kernel(const float* x, int ldx, __bf16* out, int ldo, int C, long rows) {
+    // [rows][ldx] fp32 -> [rows][ldo] bf16: channels [0, C) converted, [C, ldo) zero
+    const long total = rows * ldo;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long row = it / ldo;
+        const int c = (int)(it - row * ldo);
+        out[it] = (__bf16)(c < C ? x[row * ldx + c] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct VariantH {
+    int wm, wn, tm, tn;
+    int bm() const { return wm * tm * 32; }
+    int bn() const { return wn * tn * 32; }
+    int nt() const { return wm * wn * 64; }
+};
+
+static const VariantH kVariantsH[] = {
+    {2, 4, 4, 2},   // 0: 256 x 256, 8 waves
+    {2, 2, 4, 2},   // 1: 256 x 128, 4 waves
+    {2, 4, 4, 1},   // 2: 256 x 128, 8 waves
+    {2, 4, 2, 2},   // 3: 128 x 256, 8 waves
+    {2, 2, 2, 2},   // 4: 128 x 128, 4 waves
+    {2, 4, 2, 1},   // 5: 128 x 128, 8 waves
+    {2, 2, 2, 1},   // 6: 128 x  64, 4 waves
+    {2, 2, 1, 1},   // 7:  64 x  64, 4 waves
+};
+static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
+
+static size_t lds_bytes_h(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 128 : 256); }
+
+static int nbi_of(const VariantH& V, int taps) {
+    return taps == 9 ? (((V.bm() * 25 + 2 * V.nt() - 1) / (2 * V.nt()) + 2) / 3) : ((V.bm() * 16 / V.nt() + 7) / 8);
+}
+
+static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, TilePlan* best) {
+    const int bm = V.bm(), nt = V.nt();
+    const int lbm = ilog2(bm);
+    bool found = false;
+    const int pad = taps == 9 ? 1 : 0;
+    const int spr = taps == 9 ? 8 : 16;
+    const int maxhi = nbi_of(V, taps) * (taps == 9 ? 3 : 8);
+    for (int twl = 0; twl <= lbm; ++twl) {
+        for (int thl = 0; thl + twl <= lbm; ++thl) {
+            const int nibl = lbm - twl - thl;
+            const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
+            const int hp = NIB * (TH + 2 * pad) * (TW + 2 * pad);
+            if ((long)hp * spr > (long)maxhi * nt) continue;
+            if (lds_bytes_h(taps, hp) > 160 * 1024) continue;
+            TilePlan t;
+            t.thl = thl; t.twl = twl; t.nibl = nibl;
+            t.tiles_x = (W + TW - 1) / TW;
+            t.tiles_y = (H + TH - 1) / TH;
+            t.groups = (NI + NIB - 1) / NIB;
+            t.hp = hp;
+            t.padded = (long)t.tiles_x * t.tiles_y * t.groups * bm;
+            if (!found || t.padded < best->padded || (t.padded == best->padded && t.hp < best->hp)) {
+                *best = t;
+                found = true;
+            }
+        }
+    }
+    return found;
+}
+
+// cost model used when the caller does not pick a variant: rounds of blocks over the CUs x tile area, derated for
+// small register tiles (the Python plan builder overrides it by measuring)
+static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int N, TilePlan* out_tp) {
+    int best_v = -1;
+    TilePlan best_tp{};
+    double best_cost = 0;
+    for (int v = 0; v < kNumVariantsH; ++v) {
+        if (variant >= 0 && v != variant) continue;
+        const VariantH& V = kVariantsH[v];
+        TilePlan tp;
+        if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
+        const long nblk_n = (N + V.bn() - 1) / V.bn();
+        const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
+        const size_t lds = lds_bytes_h(taps, tp.hp);
+        int per_cu = (int)(160 * 1024 / lds);
+        const int by_waves = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;      // two waves per SIMD
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        const long slots = 256L * per_cu;
+        const long rounds = (nblocks + slots - 1) / slots;
+        double cost = (double)rounds * per_cu * V.bm() * V.bn();
+        const int rt = V.tm * V.tn;
+        cost /= (rt >= 8) ? 1.0 : (rt >= 4 ? 0.8 : (rt >= 2 ? 0.55 : 0.35));
+        if (best_v < 0 || cost < best_cost * 0.999) {
+            best_v = v; best_tp = tp; best_cost = cost;
+        }
+    }
+    if (best_v >= 0) *out_tp = best_tp;
+    return best_v;
+}
+
+template <int WM, int WN, int TM, int TN, int TAPS>
+static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS>;
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    return check_launch("nd_conv_bf16_nhwc");
+}
+
+template <int TAPS>
+static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
+    switch (v) {
+        case 0: return launch_h<2, 4, 4, 2, TAPS>(a, grid, lds, s);
+        case 1: return launch_h<2, 2, 4, 2, TAPS>(a, grid, lds, s);
+        case 2: return launch_h<2, 4, 4, 1, TAPS>(a, grid, lds, s);
+        case 3: return launch_h<2, 4, 2, 2, TAPS>(a, grid, lds, s);
+        case 4: return launch_h<2, 2, 2, 2, TAPS>(a, grid, lds, s);
+        case 5: return launch_h<2, 4, 2, 1, TAPS>(a, grid, lds, s);
+        case 6: return launch_h<2, 2, 2, 1, TAPS>(a, grid, lds, s);
+        case 7: return launch_h<2, 2, 1, 1, TAPS>(a, grid, lds, s);
+    }
+    set_error("nd_conv_bf16_nhwc: bad variant %d", v);
+    return ND_E_ARG;
+}
+
+static inline int nc64_padded(int C) { return ((C + 63) / 64 + 1) & ~1; }   // even: the 1x1 form walks two per chunk
+
+static bool use_flat_h(int taps, int flags, const float* rowbias) {
+    return taps == 1 && !(flags & (ND_CONV_IN_UP2X | ND_CONV_RES_UP2X)) && rowbias == nullptr;
+}
+
+}  // namespace nd
+
+using namespace nd;
+
+extern "C" int nd_conv_bf16_num_variants(void) { return kNumVariantsH; }
+
+extern "C" int nd_conv_bf16_variant_info(int variant, int* bm, int* bn, int* threads) {
+    if (variant < 0 || variant >= kNumVariantsH) return ND_E_ARG;
+    if (bm) *bm = kVariantsH[variant].bm();
+    if (bn) *bn = kVariantsH[variant].bn();
+    if (threads) *threads = kVariantsH[variant].nt();
+    return ND_OK;
+}
+
+extern "C" int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize) {
+    if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3)) return ND_E_ARG;
+    const int64_t nt32 = (N + 31) / 32;
+    // + 1 chunk of zeros: the fragment stream runs 3 k-steps ahead of the last real one
+    return (int64_t)(nc64_padded(C) + 1) * nt32 * ksize * ksize * 4 * 512;
+}
+
+extern "C" int nd_repack_conv_weight_bf16(const float* w, void* w_out, int N, int C, int ksize, nd_stream_t stream) {
+    const char* fn = "nd_repack_conv_weight_bf16";
+    ND_REQUIRE(w && w_out && N > 0 && C > 0 && (ksize == 1 || ksize == 3), fn, "bad arguments");
+    const long total = (long)nd_conv_bf16_weight_elems(N, C, ksize);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                       static_cast<__bf16*>(w_out), N, C, ksize * ksize, (N + 31) / 32, total);
+    return check_launch(fn);
+}
+
+extern "C" int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, int C, int64_t rows, nd_stream_t stream) {
+    const char* fn = "nd_f32_to_bf16_rows";
+    ND_REQUIRE(x && out && C > 0 && ldx >= C && ldo >= C && rows > 0, fn, "bad arguments");
+    long g = (rows * ldo + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                       static_cast<__bf16*>(out), ldo, C, (long)rows);
+    return check_launch(fn);
+}
+
+extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                 const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                 const void* residual, int ldr, void* out, int ldo,
+                                 int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream) {
+    const char* fn = "nd_conv_bf16_nhwc";
+    ND_REQUIRE(x0 && w && out, fn, "null pointer");
+    ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
+    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
+    ND_REQUIRE((C0 & 7) == 0 && (C1 & 7) == 0 && (ldx0 & 7) == 0, fn,
+               "bf16 channel counts and strides must be multiples of 8 (16-byte loads)");
+    ND_REQUIRE(ldx0 >= C0 && ldo >= N, fn, "stride smaller than channel count");
+    ND_REQUIRE(aligned16(x0) && aligned16(w), fn, "x0 / w must be 16-byte aligned");
+    if (C1 > 0) {
+        ND_REQUIRE(x1 != nullptr && (ldx1 & 7) == 0 && ldx1 >= C1 && aligned16(x1), fn,
+                   "two-source input needs an aligned x1 with ldx1 >= C1");
+    }
+    const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
+    const int res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;
+    if (up || res_up) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "2x upsampled read needs even H, W");
+    if (flags & ND_CONV_SILU_OUT) ND_REQUIRE(residual == nullptr, fn, "SILU_OUT with a residual is not supported");
+    if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
+    if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
+    ND_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (!residual || (reinterpret_cast<uintptr_t>(residual) & 7u) == 0),
+               fn, "out / residual must be 8-byte aligned");
+    ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels for 32-bit pixel indices");
+    ND_REQUIRE(variant < kNumVariantsH, fn, "bad variant");
+
+    const int taps = ksize * ksize;
+    const long M = (long)NI * H * W;
+    int pNI = NI, pH = H, pW = W;
+    if (use_flat_h(taps, flags, rowbias)) { pNI = 1; pH = 1; pW = (int)M; }
+
+    TilePlan tp{};
+    const int v = select_variant_h(variant, taps, pNI, pH, pW, N, &tp);
+    if (v < 0) return fail_arg(fn, "no tile variant fits this shape");
+    const VariantH& V = kVariantsH[v];
+
+    ConvArgsH a;
+    a.x0 = static_cast<const __bf16*>(x0);
+    a.x1 = (C1 > 0) ? static_cast<const __bf16*>(x1) : a.x0;
+    a.w = static_cast<const __bf16*>(w);
+    a.bias = bias; a.rowbias = rowbias; a.res = static_cast<const __bf16*>(residual); a.out = out;
+    a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
+    a.NI = pNI; a.H = pH; a.W = pW;
+    a.up = up; a.res_up = res_up;
+    a.Hs = pH >> up; a.Ws = pW >> up;
+    a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
+    a.NT32 = (N + 31) / 32;
+    a.NC64 = (C0 + C1 + 63) / 64;
+    a.thl = tp.thl; a.twl = tp.twl; a.nibl = tp.nibl;
+    a.tiles_x = tp.tiles_x; a.tiles_y = tp.tiles_y;
+    a.mt = tp.tiles_x * tp.tiles_y * tp.groups;
+    a.nt = (N + V.bn() - 1) / V.bn();
+    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * 2);
+    a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
+    a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
+    const int grid = a.mt * a.nt;
+    const size_t lds = lds_bytes_h(taps, tp.hp);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
+}

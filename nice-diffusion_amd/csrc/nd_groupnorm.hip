@@ -8,57 +8,95 @@
 // and the channel concatenation of the skip connection (model.py:474) read as two sources.
 //
 // HBM-bound.  Pass 1 (stats) streams the tensor once with 16-byte loads along the channel axis (fully coalesced in
-// NHWC) and reduces per-channel sums in float64 (the fp64 vector rate is far above what the stream needs, and
-// E[x^2]-E[x]^2 in float64 has no cancellation problem for fp32 data); per-(image, group) totals are combined
-// across blocks with one float64 atomic pair per block and group.  Pass 2 (apply) folds mean/rstd/gamma/beta and
-// the AdaGN scale/shift into one FMA per element (coefficients staged in LDS per block), applies SiLU and
-// optionally the 2x2 average pool, and writes 16 bytes per lane.
+// NHWC; 4 fp32 or 8 bf16 channels per lane) and accumulates per-channel sums in float64 registers (the fp64 vector
+// rate is far above what the stream needs, and E[x^2]-E[x]^2 in float64 has no cancellation problem for fp32 data).
+// Everything after the per-thread sums runs in a FIXED order, so the statistics are bitwise reproducible from run
+// to run: the pixel rows of a block are folded through LDS in row order, the channels of a group in channel order,
+// each block stores its per-(image, group) partial, and the block that draws the last ticket of its image (agent-scope
+// release / acquire around one relaxed atomic) adds the partials in block order and writes the statistics.  No
+// floating-point atomics anywhere.  Pass 2 (apply) folds mean/rstd/gamma/beta and the AdaGN scale/shift into one FMA
+// per element (coefficients staged in LDS per block), applies SiLU and optionally the 2x2 average pool, and writes
+// 16 bytes per lane.
 #include "nd_common.h"
 
 namespace nd {
 
 constexpr int GN_NT = 256;
-constexpr int GN_MAXQ = 2;   // channel quads per thread (C <= GN_NT * 4 * GN_MAXQ = 2048)
+constexpr int GN_MAXQ = 2;       // channel vectors per thread
+constexpr int GN_MAXCH = 2048;   // channels (LDS budget of the block fold: GN_NT * 8 entries of 16 bytes)
 
+typedef __bf16 gn_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct GnVec;
+template <> struct GnVec<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e];
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct GnVec<__bf16> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const __bf16* p, float (&v)[8]) {
+        const gn_bf16x8 t = *reinterpret_cast<const gn_bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    }
+    __device__ static __forceinline__ void store(__bf16* p, const float (&v)[8]) {
+        gn_bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (__bf16)v[e];
+        *reinterpret_cast<gn_bf16x8*>(p) = t;
+    }
+};
+
+template <typename T>
 struct GnSrc {
-    const float* x0;
-    const float* x1;
+    const T* x0;
+    const T* x1;
     int C0, C1, ldx0, ldx1;
 };
 
-__device__ __forceinline__ f32x4 gn_load(const GnSrc& s, size_t pix, int c) {
-    const float* p = (c < s.C0) ? (s.x0 + pix * s.ldx0 + c) : (s.x1 + pix * s.ldx1 + (c - s.C0));
-    return *reinterpret_cast<const f32x4*>(p);
+template <typename T>
+__device__ __forceinline__ const T* gn_ptr(const GnSrc<T>& s, size_t pix, int c) {
+    return (c < s.C0) ? (s.x0 + pix * s.ldx0 + c) : (s.x1 + pix * s.ldx1 + (c - s.C0));
 }
 
-// grid: (pixel chunks, NI).  Threads are laid out as PY pixel rows x QX channel quads.
+// grid: (pixel chunks, NI).  Threads are laid out as PY pixel rows x QX channel vectors.
+// ws: tickets int32 [NI] (zero on entry, left zero) followed (256-byte offset) by partials double [NI][chunks][G][2].
+template <typename T>
 __global__ void __launch_bounds__(GN_NT)
-    gn_stats_kernel(GnSrc s, const float* addvec, int ld_add, double* stats, int HW, int G, int QX, int PY,
-                    int pix_per_block) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];   // [C][2]
+    gn_stats_kernel(GnSrc<T> s, const float* addvec, int ld_add, double* stats, int* tickets, double* partials, int HW,
+                    int G, int QX, int PY, int pix_per_block) {
+    constexpr int V = GnVec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) double sh[];   // [PY][C][2], reused for [C][2] and the group sums
     const int C = s.C0 + s.C1;
-    const int CQ = C >> 2;
+    const int CQ = C / V;
     const int img = blockIdx.y;
     const int tid = threadIdx.x;
     const int tq = tid % QX;
     const int tp = tid / QX;
-    for (int i = tid; i < 2 * C; i += GN_NT) sh[i] = 0.0;
-    __syncthreads();
 
     const int p0 = blockIdx.x * pix_per_block;
     int p1 = p0 + pix_per_block;
     if (p1 > HW) p1 = HW;
 
     if (tp < PY) {
-        double sum[GN_MAXQ][4], ssq[GN_MAXQ][4];
-        f32x4 add[GN_MAXQ];
+        double sum[GN_MAXQ][V], ssq[GN_MAXQ][V];
+        float add[GN_MAXQ][V];
 #pragma unroll
         for (int j = 0; j < GN_MAXQ; ++j) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[j][e] = ssq[j][e] = 0.0;
-            add[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < V; ++e) { sum[j][e] = ssq[j][e] = 0.0; add[j][e] = 0.f; }
             const int qd = tq + j * QX;
-            if (addvec && qd < CQ) add[j] = *reinterpret_cast<const f32x4*>(addvec + (size_t)img * ld_add + qd * 4);
+            if (addvec && qd < CQ) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) add[j][e] = addvec[(size_t)img * ld_add + qd * V + e];
+            }
         }
         const size_t base = (size_t)img * HW;
         for (int p = p0 + tp; p < p1; p += PY) {
@@ -66,10 +104,11 @@ __global__ void __launch_bounds__(GN_NT)
             for (int j = 0; j < GN_MAXQ; ++j) {
                 const int qd = tq + j * QX;
                 if (qd < CQ) {
-                    f32x4 v = gn_load(s, base + p, qd * 4) + add[j];
+                    float v[V];
+                    GnVec<T>::load(gn_ptr(s, base + p, qd * V), v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double d = (double)v[e];
+                    for (int e = 0; e < V; ++e) {
+                        const double d = (double)(v[e] + add[j][e]);
                         sum[j][e] += d;
                         ssq[j][e] += d * d;
                     }
@@ -81,35 +120,77 @@ __global__ void __launch_bounds__(GN_NT)
             const int qd = tq + j * QX;
             if (qd < CQ) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(&sh[(qd * 4 + e) * 2 + 0], sum[j][e]);
-                    atomicAdd(&sh[(qd * 4 + e) * 2 + 1], ssq[j][e]);
+                for (int e = 0; e < V; ++e) {
+                    double* d = sh + ((size_t)tp * C + qd * V + e) * 2;
+                    d[0] = sum[j][e];
+                    d[1] = ssq[j][e];
                 }
             }
         }
     }
     __syncthreads();
+    // fold the PY pixel rows of every channel in row order (row 0's slot receives the channel total)
+    for (int c = tid; c < C; c += GN_NT) {
+        double a = sh[c * 2], b = sh[c * 2 + 1];
+        for (int r = 1; r < PY; ++r) {
+            a += sh[((size_t)r * C + c) * 2];
+            b += sh[((size_t)r * C + c) * 2 + 1];
+        }
+        sh[c * 2] = a;
+        sh[c * 2 + 1] = b;
+    }
+    __syncthreads();
+    // fold the channels of every group in channel order; one partial per (block, group)
     const int cpg = C / G;
-    for (int g = tid; g < G; g += GN_NT) {
+    const int nchunks = gridDim.x;
+    if (tid < G) {
         double a = 0.0, b = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
             a += sh[c * 2];
             b += sh[c * 2 + 1];
         }
-        atomicAdd(&stats[((size_t)img * G + g) * 2 + 0], a);
-        atomicAdd(&stats[((size_t)img * G + g) * 2 + 1], b);
+        double* dst = partials + (((size_t)img * nchunks + blockIdx.x) * G + tid) * 2;
+        if (nchunks == 1) dst = stats + ((size_t)img * G + tid) * 2;        // single block per image: final already
+        dst[0] = a;
+        dst[1] = b;
+    }
+    if (nchunks == 1) return;
+    // publish the partial, draw a ticket; the last block of the image adds the partials in block order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(sh);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&tickets[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == nchunks - 1) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&tickets[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    if (tid < 2 * G) {
+        const double* src = partials + (size_t)img * nchunks * G * 2 + tid;
+        double a = 0.0;
+        for (int k = 0; k < nchunks; ++k) a += src[(size_t)k * G * 2];
+        stats[(size_t)img * G * 2 + tid] = a;
     }
 }
 
 // grid: (pixel chunks, NI); LDS: coefficient pairs A[c], B[c] so that y = x*A + B
-template <bool POOL>
+template <typename T, bool POOL>
 __global__ void __launch_bounds__(GN_NT)
-    gn_apply_kernel(GnSrc s, const float* addvec, int ld_add, const double* stats, const float* gamma,
-                    const float* beta, const float* scale, const float* shift, int ld_ss, float* out, int ldo,
+    gn_apply_kernel(GnSrc<T> s, const float* addvec, int ld_add, const double* stats, const float* gamma,
+                    const float* beta, const float* scale, const float* shift, int ld_ss, T* out, int ldo,
                     int H, int W, int G, float eps, int silu, int pix_per_block) {
+    constexpr int V = GnVec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float shf[];   // A[C] | B[C]
     const int C = s.C0 + s.C1;
-    const int CQ = C >> 2;
+    const int CQ = C / V;
     const int img = blockIdx.y;
     const int tid = threadIdx.x;
     const int HW = H * W;
@@ -149,32 +230,37 @@ __global__ void __launch_bounds__(GN_NT)
     for (int it = items0 + tid; it < items1; it += GN_NT) {
         const int po = it / CQ;
         const int qd = it - po * CQ;
-        const int c = qd * 4;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(cA + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(cB + c);
-        f32x4 y;
+        const int c = qd * V;
+        float y[V];
         if (POOL) {
             const int oy = po / Wo, ox = po - oy * Wo;
             const size_t pi = ibase + (size_t)(2 * oy) * W + 2 * ox;
-            f32x4 accv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < V; ++e) y[e] = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                f32x4 v = gn_load(s, pi + (k >> 1) * W + (k & 1), c) * a + b;
-                if (silu) {
+                float v[V];
+                GnVec<T>::load(gn_ptr(s, pi + (k >> 1) * W + (k & 1), c), v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                for (int e = 0; e < V; ++e) {
+                    float t = v[e] * cA[c + e] + cB[c + e];
+                    if (silu) t = fast_silu(t);
+                    y[e] += t;
                 }
-                accv += v;
             }
-            y = accv * 0.25f;
-        } else {
-            y = gn_load(s, ibase + po, c) * a + b;
-            if (silu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = fast_silu(y[e]);
+            for (int e = 0; e < V; ++e) y[e] *= 0.25f;
+        } else {
+            float v[V];
+            GnVec<T>::load(gn_ptr(s, ibase + po, c), v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float t = v[e] * cA[c + e] + cB[c + e];
+                if (silu) t = fast_silu(t);
+                y[e] = t;
             }
         }
-        *reinterpret_cast<f32x4*>(out + (obase + po) * ldo + c) = y;
+        GnVec<T>::store(out + (obase + po) * ldo + c, y);
     }
 }
 
@@ -203,127 +289,145 @@ __global__ void gn_coeffs_kernel(const double* stats, const float* gamma, const 
     coefB[(size_t)img * ld_coef + c] = (float)b;
 }
 
-static int check_src(const char* fn, const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1, int G) {
-    ND_REQUIRE(x0 != nullptr && C0 > 0 && (C0 & 3) == 0 && (ldx0 & 3) == 0 && ldx0 >= C0 && aligned16(x0), fn,
-               "x0: channels/stride must be multiples of 4, pointer 16-byte aligned");
+static int check_src(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1, int G, int V) {
+    const int m = V - 1;
+    ND_REQUIRE(x0 != nullptr && C0 > 0 && (C0 & m) == 0 && (ldx0 & m) == 0 && ldx0 >= C0 && aligned16(x0), fn,
+               "x0: channels/stride must be multiples of 16 bytes, pointer 16-byte aligned");
     if (C1 > 0)
-        ND_REQUIRE(x1 != nullptr && (C1 & 3) == 0 && (ldx1 & 3) == 0 && ldx1 >= C1 && aligned16(x1), fn,
-                   "x1: channels/stride must be multiples of 4, pointer 16-byte aligned");
-    ND_REQUIRE(C1 >= 0 && G > 0 && (C0 + C1) % G == 0, fn, "channels not divisible by groups");
-    ND_REQUIRE(C0 + C1 <= GN_NT * 4 * GN_MAXQ, fn, "too many channels");
+        ND_REQUIRE(x1 != nullptr && (C1 & m) == 0 && (ldx1 & m) == 0 && ldx1 >= C1 && aligned16(x1), fn,
+                   "x1: channels/stride must be multiples of 16 bytes, pointer 16-byte aligned");
+    ND_REQUIRE(C1 >= 0 && G > 0 && G <= 128 && (C0 + C1) % G == 0, fn, "channels not divisible by groups");
+    ND_REQUIRE(C0 + C1 <= GN_MAXCH && (C0 + C1) / V <= GN_NT * GN_MAXQ, fn, "too many channels");
     return ND_OK;
 }
 
 // partial rows [img][row][0|1][C] (sum | sum of squares per channel) of a (two-source) tensor -> per-(image, group) sums
-// in float64, added to the array gn_stats_kernel fills.  grid (NI, 2 sources); one block per image and source.
-__global__ void __launch_bounds__(256)
+// in float64, written (not added) in a fixed order: one block per image, thread g owns group g.
+__global__ void __launch_bounds__(128)
     gn_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, double* stats, int G) {
-    __shared__ double sh[2 * 64];          // [G][2], G <= 64
     const int img = blockIdx.x;
-    const int src = blockIdx.y;
-    const float* pp = src ? p1 : p0;
-    const int Cs = src ? C1 : C0, rows_all = src ? rows1 : rows0, cbase = src ? C0 : 0;
-    // blockIdx.z splits the rows
-    const int rchunk = (rows_all + gridDim.z - 1) / gridDim.z;
-    const int rbeg = blockIdx.z * rchunk;
-    const int rows = (rbeg + rchunk < rows_all) ? rbeg + rchunk : rows_all;   // end (exclusive)
-    if (rbeg >= rows) return;
+    const int g = threadIdx.x;
+    if (g >= G) return;
     const int cpg = (C0 + C1) / G;
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) sh[i] = 0.0;
-    __syncthreads();
-    // thread t owns channel c = t % Cs (fixed group) and walks the rows t / Cs, t / Cs + blockDim.x / Cs, ...
-    if (Cs <= (int)blockDim.x) {
-        const int per = blockDim.x / Cs;
-        const int c = threadIdx.x % Cs, r0 = threadIdx.x / Cs;
-        if (r0 < per) {
-            double a = 0.0, b = 0.0;
-            for (int r = rbeg + r0; r < rows; r += per) {
-                const float* q = pp + (((size_t)img * rows_all + r) * 2) * Cs + c;
-                a += (double)q[0];
-                b += (double)q[Cs];
-            }
-            const int g = (cbase + c) / cpg;
-            atomicAdd(&sh[2 * g], a);
-            atomicAdd(&sh[2 * g + 1], b);
-        }
-    } else {
-        for (int c = threadIdx.x; c < Cs; c += blockDim.x) {
-            double a = 0.0, b = 0.0;
-            for (int r = rbeg; r < rows; ++r) {
-                const float* q = pp + (((size_t)img * rows_all + r) * 2) * Cs + c;
-                a += (double)q[0];
-                b += (double)q[Cs];
-            }
-            const int g = (cbase + c) / cpg;
-            atomicAdd(&sh[2 * g], a);
-            atomicAdd(&sh[2 * g + 1], b);
+    double a = 0.0, b = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const bool second = c >= C0;
+        const float* pp = second ? p1 : p0;
+        const int Cs = second ? C1 : C0, rows = second ? rows1 : rows0, cc = second ? c - C0 : c;
+        for (int r = 0; r < rows; ++r) {
+            const float* q = pp + (((size_t)img * rows + r) * 2) * Cs + cc;
+            a += (double)q[0];
+            b += (double)q[Cs];
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x)
-        if (sh[i] != 0.0) atomicAdd(&stats[(size_t)img * G * 2 + i], sh[i]);
+    stats[((size_t)img * G + g) * 2 + 0] = a;
+    stats[((size_t)img * G + g) * 2 + 1] = b;
 }
 
-}  // namespace nd
+// pixel chunks per image of the statistics pass: enough blocks to fill the chip (~2048), at least 4 pixels per
+// pixel-row of threads
+static void stats_geometry(int NI, int HW, int CQ, int* QX, int* PY, int* ppb, int* chunks) {
+    *QX = CQ < GN_NT ? CQ : (CQ + GN_MAXQ - 1) / GN_MAXQ;
+    *PY = GN_NT / *QX;
+    if (*PY < 1) *PY = 1;
+    int ch = (2048 + NI - 1) / NI;
+    int pb = (HW + ch - 1) / ch;
+    if (pb < 4 * *PY) pb = 4 * *PY;
+    *ppb = pb;
+    *chunks = (HW + pb - 1) / pb;
+}
 
-using namespace nd;
-
-extern "C" int nd_groupnorm_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                                       const float* addvec, int ld_add, double* stats, int NI, int HW, int G,
-                                       nd_stream_t stream) {
-    const char* fn = "nd_groupnorm_stats_nhwc";
-    int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G);
-    if (rc) return rc;
-    ND_REQUIRE(stats != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
-    if (addvec) ND_REQUIRE((ld_add & 3) == 0 && aligned16(addvec), fn, "addvec alignment");
-    const int C = C0 + C1, CQ = C >> 2;
-    const int QX = CQ < GN_NT ? CQ : (CQ + GN_MAXQ - 1) / GN_MAXQ;
+template <typename T>
+static int launch_stats(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                        const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW, int G,
+                        hipStream_t st) {
+    constexpr int V = GnVec<T>::N;
+    const int C = C0 + C1, CQ = C / V;
+    int QX, PY, ppb, chunks;
+    stats_geometry(NI, HW, CQ, &QX, &PY, &ppb, &chunks);
     ND_REQUIRE(QX <= GN_NT, fn, "too many channels");
-    int PY = GN_NT / QX;
-    if (PY < 1) PY = 1;
-    // enough blocks to fill the chip (~2048), at least 4 pixels per pixel-row of threads
-    int chunks = (2048 + NI - 1) / NI;
-    int ppb = (HW + chunks - 1) / chunks;
-    if (ppb < 4 * PY) ppb = 4 * PY;
-    chunks = (HW + ppb - 1) / ppb;
-    GnSrc s{x0, C1 > 0 ? x1 : x0, C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, NI), dim3(GN_NT), (size_t)C * 2 * sizeof(double),
-                       reinterpret_cast<hipStream_t>(stream), s, addvec, ld_add, stats, HW, G, QX, PY, ppb);
+    ND_REQUIRE(chunks == 1 || workspace != nullptr, fn, "workspace needed (nd_groupnorm_stats_workspace_bytes)");
+    GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
+    int* tickets = static_cast<int*>(workspace);
+    double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + (((size_t)NI * 4 + 255) & ~(size_t)255));
+    const size_t lds = (size_t)PY * C * 2 * sizeof(double);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats, tickets,
+                       partials, HW, G, QX, PY, ppb);
     return check_launch(fn);
 }
 
-extern "C" int nd_groupnorm_apply_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                                       const float* addvec, int ld_add, const double* stats,
-                                       const float* gamma, const float* beta,
-                                       const float* scale, const float* shift, int ld_ss,
-                                       float* out, int ldo, int NI, int H, int W, int G, float eps, int flags,
-                                       nd_stream_t stream) {
-    const char* fn = "nd_groupnorm_apply_nhwc";
-    int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G);
-    if (rc) return rc;
-    const int C = C0 + C1, CQ = C >> 2;
-    ND_REQUIRE(stats && gamma && beta && out && NI > 0 && H > 0 && W > 0, fn, "bad arguments");
-    ND_REQUIRE((ldo & 3) == 0 && ldo >= C && aligned16(out), fn, "out alignment");
-    ND_REQUIRE((scale == nullptr) == (shift == nullptr), fn, "scale and shift go together");
+template <typename T>
+static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                        const float* addvec, int ld_add, const double* stats, const float* gamma, const float* beta,
+                        const float* scale, const float* shift, int ld_ss, void* out, int ldo, int NI, int H, int W,
+                        int G, float eps, int flags, hipStream_t st) {
+    constexpr int V = GnVec<T>::N;
+    const int C = C0 + C1, CQ = C / V;
+    ND_REQUIRE((ldo & (V - 1)) == 0 && ldo >= C && aligned16(out), fn, "out alignment");
     const bool pool = (flags & ND_GN_POOL2) != 0;
-    if (pool) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "POOL2 needs even H, W");
     const int HWo = pool ? (H >> 1) * (W >> 1) : H * W;
     int chunks = (2048 + NI - 1) / NI;
     int ppb = (HWo + chunks - 1) / chunks;
     const int min_ppb = (GN_NT * 4 + CQ - 1) / CQ;   // >= 4 items per thread
     if (ppb < min_ppb) ppb = min_ppb;
     chunks = (HWo + ppb - 1) / ppb;
-    GnSrc s{x0, C1 > 0 ? x1 : x0, C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
+    GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
     const size_t lds = (size_t)C * 2 * sizeof(float);
     const int silu = (flags & ND_GN_SILU) ? 1 : 0;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (pool)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
-                           gamma, beta, scale, shift, ld_ss, out, ldo, H, W, G, eps, silu, ppb);
+        hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
+                           gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
-                           gamma, beta, scale, shift, ld_ss, out, ldo, H, W, G, eps, silu, ppb);
+        hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
+                           gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
     return check_launch(fn);
+}
+
+}  // namespace nd
+
+using namespace nd;
+
+extern "C" int64_t nd_groupnorm_stats_workspace_bytes(int NI, int HW, int C, int G, int dtype) {
+    if (NI <= 0 || HW <= 0 || C <= 0 || G <= 0 || (dtype != ND_DT_F32 && dtype != ND_DT_BF16)) return ND_E_ARG;
+    int QX, PY, ppb, chunks;
+    stats_geometry(NI, HW, C / (dtype == ND_DT_BF16 ? 8 : 4), &QX, &PY, &ppb, &chunks);
+    return (int64_t)(((size_t)NI * 4 + 255) & ~(size_t)255) + (int64_t)NI * chunks * G * 2 * 8;
+}
+
+extern "C" int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                       const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW,
+                                       int G, int dtype, nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_stats_nhwc";
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G, dtype == ND_DT_BF16 ? 8 : 4);
+    if (rc) return rc;
+    ND_REQUIRE(stats != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
+    ND_REQUIRE(workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, fn, "workspace must be 256-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ND_DT_BF16)
+        return launch_stats<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, workspace, NI, HW, G, st);
+    return launch_stats<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, workspace, NI, HW, G, st);
+}
+
+extern "C" int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                       const float* addvec, int ld_add, const double* stats,
+                                       const float* gamma, const float* beta,
+                                       const float* scale, const float* shift, int ld_ss,
+                                       void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,
+                                       nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_apply_nhwc";
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G, dtype == ND_DT_BF16 ? 8 : 4);
+    if (rc) return rc;
+    ND_REQUIRE(stats && gamma && beta && out && NI > 0 && H > 0 && W > 0, fn, "bad arguments");
+    ND_REQUIRE((scale == nullptr) == (shift == nullptr), fn, "scale and shift go together");
+    if (flags & ND_GN_POOL2) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "POOL2 needs even H, W");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ND_DT_BF16)
+        return launch_apply<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, gamma, beta, scale, shift,
+                                    ld_ss, out, ldo, NI, H, W, G, eps, flags, st);
+    return launch_apply<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, gamma, beta, scale, shift, ld_ss,
+                               out, ldo, NI, H, W, G, eps, flags, st);
 }
 
 extern "C" int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
@@ -341,14 +445,10 @@ extern "C" int nd_groupnorm_coeffs(const double* stats, const float* gamma, cons
 extern "C" int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
                                                double* stats, int NI, int G, nd_stream_t stream) {
     const char* fn = "nd_groupnorm_stats_from_partials";
-    ND_REQUIRE(p0 && stats && NI > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 64 && (C0 + C1) % G == 0, fn,
+    ND_REQUIRE(p0 && stats && NI > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 128 && (C0 + C1) % G == 0, fn,
                "bad arguments");
     if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
-    const int rmax = rows0 > rows1 ? rows0 : rows1;
-    int splits = rmax / 8;
-    if (splits < 1) splits = 1;
-    if (splits > 16) splits = 16;
-    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(NI, C1 > 0 ? 2 : 1, splits), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), p0, C0, rows0, C1 > 0 ? p1 : p0, C1, rows1, stats, G);
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
+                       rows0, C1 > 0 ? p1 : p0, C1, rows1, stats, G);
     return check_launch(fn);
 }

@@ -93,6 +93,29 @@ __global__ void avgpool2x_kernel(const float* x, int ldx, float* out, int ldo, i
     }
 }
 
+// bf16 form: 8 channels (16 bytes) per thread, averaged in fp32
+typedef __bf16 pw_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void avgpool2x_bf16_kernel(const __bf16* x, int ldx, __bf16* out, int ldo, int H, int W, int CQ, long total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int qd = (int)(it % CQ);
+        long pix = it / CQ;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const long img = pix / Ho;
+        const size_t s0 = ((size_t)(img * H + 2 * oy) * W + 2 * ox) * ldx + qd * 8;
+        const pw_bf16x8 a = *reinterpret_cast<const pw_bf16x8*>(x + s0);
+        const pw_bf16x8 b = *reinterpret_cast<const pw_bf16x8*>(x + s0 + ldx);
+        const pw_bf16x8 c = *reinterpret_cast<const pw_bf16x8*>(x + s0 + (size_t)W * ldx);
+        const pw_bf16x8 d = *reinterpret_cast<const pw_bf16x8*>(x + s0 + (size_t)W * ldx + ldx);
+        pw_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(((float)a[e] + (float)b[e] + (float)c[e] + (float)d[e]) * 0.25f);
+        *reinterpret_cast<pw_bf16x8*>(out + ((size_t)(img * Ho + oy) * Wo + ox) * ldo + qd * 8) = o;
+    }
+}
+
 // ---- layout --------------------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int C, int HW, int ld, long total) {
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -260,11 +283,21 @@ extern "C" int nd_space_to_depth2_nhwc(const float* x, int ldx, float* out, int 
     return check_launch(fn);
 }
 
-extern "C" int nd_avgpool2x_nhwc(const float* x, int ldx, float* out, int ldo, int NI, int H, int W, int C,
+extern "C" int nd_avgpool2x_nhwc(const void* xv, int ldx, void* outv, int ldo, int NI, int H, int W, int C, int dtype,
                                  nd_stream_t stream) {
     const char* fn = "nd_avgpool2x_nhwc";
-    ND_REQUIRE(x && out && NI > 0 && H > 1 && W > 1 && C > 0, fn, "bad arguments");
+    ND_REQUIRE(xv && outv && NI > 0 && H > 1 && W > 1 && C > 0, fn, "bad arguments");
     ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "H and W must be even");
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    if (dtype == ND_DT_BF16) {
+        ND_REQUIRE((C & 7) == 0 && (ldx & 7) == 0 && (ldo & 7) == 0 && aligned16(xv) && aligned16(outv), fn, "alignment");
+        const long total = (long)NI * (H >> 1) * (W >> 1) * (C >> 3);
+        hipLaunchKernelGGL(avgpool2x_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream),
+                           static_cast<const __bf16*>(xv), ldx, static_cast<__bf16*>(outv), ldo, H, W, C >> 3, total);
+        return check_launch(fn);
+    }
+    const float* x = static_cast<const float*>(xv);
+    float* out = static_cast<float*>(outv);
     ND_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && aligned16(x) && aligned16(out), fn, "alignment");
     const long total = (long)NI * (H >> 1) * (W >> 1) * (C >> 2);
     hipLaunchKernelGGL(avgpool2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ND_STREAM(stream), x, ldx, out,

@@ -54,13 +54,14 @@ def _pad4(n):
 
 
 class Act:
-    """NHWC activation: flat fp32 buffer + geometry."""
-    __slots__ = ('t', 'NI', 'H', 'W', 'C', 'ld', 'cs')
+    """NHWC activation: flat buffer (allocated as fp32 words; holds fp32 or bf16 elements) + geometry."""
+    __slots__ = ('t', 'NI', 'H', 'W', 'C', 'ld', 'cs', 'bf16')
 
-    def __init__(self, t, NI, H, W, C, ld=None):
+    def __init__(self, t, NI, H, W, C, ld=None, bf16=False):
         self.t, self.NI, self.H, self.W, self.C = t, NI, H, W, C
         self.ld = C if ld is None else ld
         self.cs = None      # (('chpart', float offset), rows per image): partial output statistics left by the producing conv
+        self.bf16 = bf16
 
     @property
     def ptr(self):
@@ -123,10 +124,18 @@ _CLOCK_SETTLED = [False]
 
 
 class UNetPlan:
-    def __init__(self, model, NI):
+    def __init__(self, model, NI, dtype='fp32'):
+        """``dtype``: 'fp32' (exact-fp32 MFMA / Winograd kernels, the reference's arithmetic) or 'bf16' (BASELINE
+        configs[3], [4]: bf16 activations and weights in HBM, fp32 accumulation, fp32 GroupNorm statistics, fp32
+        embedding MLP, fp32 x_t / model output at the sampler's edge)."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError('dtype must be fp32 or bf16')
         self.lib = _hip.load()
         self.model = model
         self.NI = NI
+        self.dtype = dtype
+        self.bf16 = dtype == 'bf16'
+        self.dt = _hip.DT_BF16 if self.bf16 else _hip.DT_F32
         dev = next(model.parameters()).device
         _hip.require_device(next(model.parameters()), 'model parameters')
         if dev.index is None:
@@ -155,7 +164,7 @@ class UNetPlan:
         self.y_in = torch.zeros(NI, dtype=torch.int64, device=dev) if model.conditional else None
         self.out = torch.empty(NI * R * R * self.Cout_p, **f32)
         self._gn_slots = 0
-        self._gn_users = []     # ops needing the stats base pointer patched in
+        self._gn_ws_bytes = 256  # GroupNorm statistics workspace (tickets + per-block partials), shared by all norms
         self._cs_floats = 0     # fp32 words of partial output statistics (see conv(want_stats=True))
         self.taps = []          # (module name, number of ops emitted when its output is complete, Act): debug hook
         _load_tune_cache()
@@ -171,7 +180,8 @@ class UNetPlan:
         self.meta.append(dict(label=label, fn=fn.__name__, flops=flops, variant=variant, ksize=ksize, shape=shape))
 
     def _new(self, NI, H, W, C):
-        return Act(self.pool.take(NI * H * W * C), NI, H, W, C)
+        n = NI * H * W * C
+        return Act(self.pool.take((n + 1) // 2 if self.bf16 else n), NI, H, W, C, bf16=self.bf16)
 
     def _release(self, act):
         if isinstance(act, Act) and act.t is not None:
@@ -221,6 +231,9 @@ class UNetPlan:
         module's parameter (packed here); output spatial size is src's, doubled when CONV_IN_UP2X is set.  For 3x3
         convolutions on even sizes the Winograd F(2x2,3x3) kernel competes with the direct kernel's tile shapes and
         the fastest measured implementation is kept."""
+        if self.bf16:
+            return self._conv_bf16(src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label,
+                                   pad_c_to)
         gn = [None, None, 0]
         tmp = None
         if isinstance(src, Normed):
@@ -290,9 +303,93 @@ class UNetPlan:
         args = [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', nm.slot),
                 nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr,
                 nm.ld_ss, out.ptr, out.ld, nm.src.NI, nm.src.H, nm.src.W, GN_GROUPS, GN_EPS,
-                _hip.GN_SILU if nm.silu else 0]
+                _hip.GN_SILU if nm.silu else 0, self.dt]
         self._emit(self.lib.nd_groupnorm_apply_nhwc, args, 'gn.apply')
         return out
+
+    # ------------------------------------------------------------------------------------------------ bf16 convolution
+    def _packed_bf16(self, weight, pad_c_to=None):
+        """fp32 OIHW / [N,C,1] / [N,C] weight -> bf16 MFMA-fragment order, once, on the device (the bf16 half of the
+        weight ingest: the checkpoint stays fp32, the cast happens in the repack)."""
+        w = weight.detach().contiguous()
+        N, C = w.shape[0], w.shape[1]
+        k = w.shape[2] if w.dim() == 4 else 1
+        if pad_c_to is not None and pad_c_to != C:
+            wp = torch.zeros((N, pad_c_to) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            wp[:, :C] = w
+            w, C = wp, pad_c_to
+        n = self.lib.nd_conv_bf16_weight_elems(N, C, k)
+        assert n > 0
+        out = torch.empty(n, dtype=torch.bfloat16, device=self.device)
+        _hip.check(self.lib.nd_repack_conv_weight_bf16(w.data_ptr(), out.data_ptr(), N, C, k, self._stream()),
+                   'nd_repack_conv_weight_bf16')
+        return out
+
+    def _conv_bf16(self, src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label, pad_c_to):
+        tmp = None
+        if isinstance(src, Normed):
+            tmp = self._materialise(src)          # bf16 apply pass (HBM-bound, half the bytes of the fp32 one)
+            src, src2 = tmp, None
+        up = 1 if (flags & _hip.CONV_IN_UP2X) else 0
+        NI, H, W = src.NI, src.H << up, src.W << up
+        if out is None:
+            out = self._new(NI, H, W, N)
+        if not out.bf16:
+            flags |= _hip.CONV_OUT_F32
+        C1 = 0 if src2 is None else src2.C
+        wq = self._packed_bf16(weight, pad_c_to)
+        self.keep.append(wq)
+        self.packed_floats += wq.numel() // 2
+        head = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld,
+                wq.data_ptr(), bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
+                0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N, ksize, flags]
+        fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
+        key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None)
+        var = self._pick_bf16(key, fl, head)
+        self._emit(self.lib.nd_conv_bf16_nhwc, head + [var], label, flops=fl, variant=('bf16', var), ksize=ksize,
+                   shape=(NI, H, W, src.C + C1, N))
+        self.flops += fl
+        self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
+        if tmp is not None:
+            self._release(tmp)
+        return out
+
+    def _pick_bf16(self, key, flops, head):
+        """Tile variant for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with ND_AUTOTUNE=0,
+        else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per shape."""
+        if not _autotune_enabled() or flops < 2e8:
+            return -1
+        ck = (self.device.index,) + key
+        if ck in _TUNED:
+            return _TUNED[ck][1]
+        stream = self._stream()
+        fn = self.lib.nd_conv_bf16_nhwc
+        best, best_ms = -1, None
+        for v in range(self.lib.nd_conv_bf16_num_variants()):
+            args = head + [v]
+            if fn(*args, stream) != 0:
+                continue                                  # this tile shape does not fit the problem
+            if not _CLOCK_SETTLED[0]:
+                t0 = time.time()
+                while time.time() - t0 < 1.0:
+                    for _ in range(8):
+                        fn(*args, stream)
+                    torch.cuda.synchronize()
+                _CLOCK_SETTLED[0] = True
+            t = None
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(6):
+                    fn(*args, stream)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / 6
+                t = ms if t is None else min(t, ms)
+            if best_ms is None or t < best_ms:
+                best, best_ms = v, t
+        _TUNED[ck] = ('bf16', best)
+        return best
 
     def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
         """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct
@@ -379,14 +476,18 @@ class UNetPlan:
                        [src.cs[0], src.C, src.cs[1], None if src2 is None else src2.cs[0], 0 if src2 is None else src2.C,
                         0 if src2 is None else src2.cs[1], ('gnstats', slot), NI, GN_GROUPS], label + '.stats_from_partials')
         else:
-            stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS]
+            ws = self.lib.nd_groupnorm_stats_workspace_bytes(NI, H * W, C, GN_GROUPS, self.dt)
+            assert ws > 0
+            self._gn_ws_bytes = max(self._gn_ws_bytes, ws)
+            stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), ('gnws', 0), NI, H * W,
+                          GN_GROUPS, self.dt]
             self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
         if pool:
             out = self._new(NI, H // 2, W // 2, C)
             flags = (_hip.GN_SILU if silu else 0) | _hip.GN_POOL2
             apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot),
                           norm.weight.detach().data_ptr(), norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
-                          out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags]
+                          out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags, self.dt]
             self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
             return out
         return Normed(src=src, src2=src2, C=C, silu=silu, norm=norm, scale_ptr=scale_ptr, shift_ptr=shift_ptr,
@@ -443,6 +544,13 @@ class UNetPlan:
 
         # ---- the UNet proper
         x = Act(self.x_in, NI, R, R, self.Cin_p)
+        if self.bf16:
+            # x_t stays fp32 (NHWC4) for the sampler update; the UNet reads a bf16 copy padded to 8 channels (16 bytes)
+            xb = Act(torch.zeros(NI * R * R * 8 // 2, **f32), NI, R, R, 8, bf16=True)
+            self.keep.append(xb.t)
+            self._emit(lib.nd_f32_to_bf16_rows, [self.x_in.data_ptr(), self.Cin_p, xb.ptr, 8, self.Cin, NI * R * R],
+                       'x_to_bf16')
+            x = xb
         skips = []
         # every downsampling block's output is a skip connection: it stays alive until the matching pop below
         for i, block in enumerate(m.downsampling):
@@ -455,16 +563,21 @@ class UNetPlan:
                                     name='upsampling.{}'.format(i))
         # output head: GN -> SiLU -> conv3x3 (model.py:446-449)
         h = self.groupnorm(x_cur, m.out[0], silu=True, label='out.0')
-        out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)
+        out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)      # fp32 in both modes
         self.conv(h, m.out[2].weight, m.out[2].bias.detach().data_ptr(), self.Cout, 3,
                   out=out_act, label='conv3x3')
         self._release(x_cur)
 
-        # ---- GroupNorm statistics arena (float64 [slots][NI][32][2]); zeroed at the start of every run
+        # ---- GroupNorm statistics arena (float64 [slots][NI][32][2], fully written by every forward) and the statistics
+        #      workspace: NI int32 tickets (zeroed at the start of every run; the kernels leave them zero) + partials
         n_gn = max(1, self._gn_slots) * NI * GN_GROUPS * 2
         self.gn_stats = torch.zeros(n_gn, dtype=torch.float64, device=dev)
         slot_bytes = NI * GN_GROUPS * 2 * 8
         base = self.gn_stats.data_ptr()
+        self.gn_ws = torch.zeros((self._gn_ws_bytes + 7) // 8, dtype=torch.float64, device=dev)
+        assert self.gn_ws.data_ptr() % 256 == 0
+        self.gn_tickets = self.gn_ws[:(NI * 4 + 7) // 8]
+        ws_base = self.gn_ws.data_ptr()
         # partial output statistics written by the position-split convs (fully rewritten every forward)
         self.ch_partials = torch.zeros(max(4, self._cs_floats), dtype=torch.float32, device=dev)
         cs_base = self.ch_partials.data_ptr()
@@ -474,6 +587,8 @@ class UNetPlan:
                 return base + a[1] * slot_bytes
             if isinstance(a, tuple) and a and a[0] == 'chpart':
                 return cs_base + a[1] * 4
+            if isinstance(a, tuple) and a and a[0] == 'gnws':
+                return ws_base
             return a
         bound = []
         for fn, args, label in self.ops:
@@ -542,7 +657,7 @@ class UNetPlan:
         tmp = None
         if mode == 'down':
             tmp = self._new(NI, x.H // 2, x.W // 2, x.C)
-            self._emit(lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, tmp.ptr, tmp.ld, NI, x.H, x.W, x.C], 'avgpool')
+            self._emit(lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, tmp.ptr, tmp.ld, NI, x.H, x.W, x.C, self.dt], 'avgpool')
             xs, xs2 = tmp, None
         else:
             xs, xs2 = x, x2
@@ -583,7 +698,7 @@ class UNetPlan:
             offs = (0, C, 2 * C, hd)
         else:
             offs = (0, hd, 2 * hd, 3 * hd)
-        self._emit(self.lib.nd_attention_nhwc, [qkv.ptr, qkv.ld, a.ptr, a.ld, NI, T, nh, hd, offs[0], offs[1], offs[2],
+        self._emit(self.lib.nd_attention_bf16_nhwc if self.bf16 else self.lib.nd_attention_nhwc, [qkv.ptr, qkv.ld, a.ptr, a.ld, NI, T, nh, hd, offs[0], offs[1], offs[2],
                                                 offs[3], float(ab.scale)], 'attention',
                    flops=4 * NI * nh * T * T * hd)
         self.flops += 4 * NI * nh * T * T * hd
@@ -616,10 +731,14 @@ class UNetPlan:
                 w2 = w2.reshape(N, 4 * C, 3, 3).contiguous()
                 self.keep.append(w2)
                 s2d = self._new(NI, x.H // 2, x.W // 2, 4 * C)
-                self._emit(self.lib.nd_space_to_depth2_nhwc, [x.ptr, x.ld, s2d.ptr, s2d.ld, NI, x.H, x.W, C], 'space_to_depth')
+                e = 2 if self.bf16 else 1      # pure data movement: bf16 pairs travel as fp32 words
+                self._emit(self.lib.nd_space_to_depth2_nhwc, [x.ptr, x.ld // e, s2d.ptr, s2d.ld // e, NI, x.H, x.W, C // e],
+                           'space_to_depth')
                 out = self.conv(s2d, w2, layer.conv.bias.detach().data_ptr(), N, 3, label='conv_s2')
                 self._release(s2d)
                 return out
+            if self.bf16:
+                raise _hip.NdHipError('bf16 path: stride-2 convolution on odd sizes is not supported (use dtype fp32)')
             Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
             out = self._new(NI, Ho, Wo, N)
             self._emit(self.lib.nd_conv_direct_nhwc, [x.ptr, x.C, x.ld, w.data_ptr(),
@@ -627,7 +746,7 @@ class UNetPlan:
                                                       x.W, N, 3, 2, 1], 'conv_s2')
             return out
         out = self._new(NI, x.H // 2, x.W // 2, x.C)
-        self._emit(self.lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'avgpool')
+        self._emit(self.lib.nd_avgpool2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C, self.dt], 'avgpool')
         return out
 
     def _upsample(self, layer, x):
@@ -638,7 +757,8 @@ class UNetPlan:
             return self.conv(x, layer.conv.weight, layer.conv.bias.detach().data_ptr(), N, 3,
                              flags=_hip.CONV_IN_UP2X, label='conv3x3')
         out = self._new(NI, 2 * x.H, 2 * x.W, x.C)
-        self._emit(self.lib.nd_upsample2x_nhwc, [x.ptr, x.ld, out.ptr, out.ld, NI, x.H, x.W, x.C], 'upsample')
+        e = 2 if self.bf16 else 1
+        self._emit(self.lib.nd_upsample2x_nhwc, [x.ptr, x.ld // e, out.ptr, out.ld // e, NI, x.H, x.W, x.C // e], 'upsample')
         return out
 
     # ------------------------------------------------------------------------------------------------ run
@@ -653,7 +773,7 @@ class UNetPlan:
         """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_stats.zero_()
+        self.gn_tickets.zero_()
         for fn, args, label in self.ops:
             rc = fn(*args, stream)
             if rc != 0:
@@ -665,7 +785,7 @@ class UNetPlan:
         Buffers are recycled by later launches, so each output is copied out right after its last producing launch."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_stats.zero_()
+        self.gn_tickets.zero_()
         got, k = {}, 0
         for idx, (fn, args, label) in enumerate(self.ops):
             rc = fn(*args, stream)
@@ -673,8 +793,9 @@ class UNetPlan:
                 raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))
             while k < len(self.taps) and self.taps[k][1] == idx + 1:
                 name, _, a = self.taps[k]
-                v = a.t[:a.NI * a.H * a.W * a.ld].view(a.NI, a.H, a.W, a.ld)[..., :a.C]
-                got[name] = v.permute(0, 3, 1, 2).contiguous()
+                flat = a.t.view(torch.bfloat16) if a.bf16 else a.t
+                v = flat[:a.NI * a.H * a.W * a.ld].view(a.NI, a.H, a.W, a.ld)[..., :a.C]
+                got[name] = v.permute(0, 3, 1, 2).float().contiguous()
                 k += 1
         assert k == len(self.taps)
         return got
@@ -684,7 +805,7 @@ class UNetPlan:
         launch: the plan's meta (label, entry point, flops, conv variant) plus ``ms``."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_stats.zero_()
+        self.gn_tickets.zero_()
         evs = []
         for fn, args, label in self.ops:
             a = torch.cuda.Event(enable_timing=True)

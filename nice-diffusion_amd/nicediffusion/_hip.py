@@ -14,6 +14,9 @@ CONV_IN_UP2X = 1
 CONV_RES_UP2X = 2
 CONV_SILU_OUT = 4
 CONV_GN_SILU = 8
+CONV_OUT_F32 = 16
+DT_F32 = 0
+DT_BF16 = 1
 GN_SILU = 1
 GN_POOL2 = 2
 VAR_FIXED = 0
@@ -42,12 +45,17 @@ SIGNATURES = {
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _vp],
-    'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     'nd_groupnorm_apply_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
-                                _i, _i, _i, _i, _f, _i, _vp],
+                                _i, _i, _i, _i, _f, _i, _i, _vp],
+    'nd_conv_bf16_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                          _i, _i, _i, _i, _i, _i, _i, _vp],
+    'nd_repack_conv_weight_bf16': [_vp, _vp, _i, _i, _i, _vp],
+    'nd_f32_to_bf16_rows': [_vp, _i, _vp, _i, _i, _i64, _vp],
+    'nd_attention_bf16_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     'nd_attention_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     'nd_upsample2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    'nd_avgpool2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_avgpool2x_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'nd_space_to_depth2_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_nchw_to_nhwc': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_nhwc_to_nchw': [_vp, _vp, _i, _i, _i, _i, _vp],
@@ -63,6 +71,10 @@ _SPECIAL = {
     'nd_version': ([], _i),
     'nd_conv_num_variants': ([], _i),
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
+    'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
+    'nd_conv_bf16_num_variants': ([], _i),
+    'nd_conv_bf16_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
+    'nd_groupnorm_stats_workspace_bytes': ([_i, _i, _i, _i, _i], _i64),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_winograd_stats_variant': ([], _i),

@@ -169,6 +169,9 @@ class DiffusionModel(nn.Module):
                                                        padding=(1, 1))))
         self._plans = {}
         self.verify_weights = True     # digest the weights on the device before reusing a cached plan
+        # arithmetic of the forward: 'fp32' = the reference's (exact fp32 MFMA kernels); 'bf16' = bf16 activations and
+        # weights with fp32 accumulation (parameters stay fp32; the cast happens in the plan's weight repack)
+        self.compute_dtype = 'fp32'
 
     # -------------------------------------------------------------------------------------------- plan management
     def _residual_blocks(self):
@@ -214,7 +217,8 @@ class DiffusionModel(nn.Module):
         with torch.cuda.device(dev):
             sig = self._weight_signature()
             digest = self._weight_digest() if self.verify_weights else None
-            plan = self._plans.get(batch)
+            pkey = (batch, self.compute_dtype)
+            plan = self._plans.get(pkey)
             if plan is not None and (plan.weight_signature != sig or plan.weight_digest != digest):
                 self.invalidate_plans()          # the other batch sizes' plans hold the same stale copies
                 plan = None
@@ -223,11 +227,11 @@ class DiffusionModel(nn.Module):
                     if p.dtype != torch.float32:
                         raise _hip.NdHipError('parameters must be fp32')
                 with torch.no_grad():
-                    plan = UNetPlan(self, batch)
+                    plan = UNetPlan(self, batch, self.compute_dtype)
                 plan.weight_digest = digest
                 if len(self._plans) >= 4:
                     self._plans = {}
-                self._plans[batch] = plan
+                self._plans[pkey] = plan
         return plan
 
     def _apply(self, fn, *a, **k):

@@ -1,0 +1,410 @@
+"""bf16 path (BASELINE configs[3], [4]) on a real MI355X, through the C ABI.
+
+The reference has no bf16 arithmetic (utils.py:83 parses --use_fp16 and never reads it; model.py:517 is fp32), so the
+bar is stated here and in DESIGN.md:
+  * kernel level: each bf16 kernel against a float64 CPU statement of the same op on the SAME bf16-rounded operands --
+    what remains is fp32 accumulation order and the final rounding of the output to bf16 (half an ulp = 2^-9 relative);
+  * model level: the bf16 forward against the reference's fp32 goldens / the fp32 HIP forward of the same weights:
+    relative rms error <= 3.5e-2 and max error <= 8e-2 of the output's max magnitude per forward (every activation is
+    rounded to 8 significant bits ~50 times along the deepest path: measured 1.4e-2 .. 2.4e-2 rms); a teacher-forced
+    sampler step moves x_{t-1} by <= 3e-2 (x is O(1)).  Measured values are printed by the tests and recorded in DESIGN.md.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nicediffusion import _hip
+from nicediffusion import default_args as DA
+from nicediffusion.diffusion import Diffusion
+from nicediffusion.model import DiffusionModel
+from oracle import unet_oracle as UO
+from oracle import diffusion_oracle as DO
+from tests.cases import TINY_CFGS
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def lib():
+    return _hip.load()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x):
+    """bf16-rounded copy (round to nearest even, as the kernels' conversions do), still fp32."""
+    return x.to(BF).float()
+
+
+def nhwc_bf(x, ld=None):       # [B,C,H,W] cpu fp32 -> flat NHWC bf16 on the device (channels padded to ld with garbage-free zeros)
+    B, C, H, W = x.shape
+    ld = C if ld is None else ld
+    t = torch.zeros(B, H, W, ld, dtype=BF)
+    t[..., :C] = x.permute(0, 2, 3, 1).to(BF)
+    return t.contiguous().to(DEV)
+
+
+def from_nhwc(t, B, H, W, C, ld=None):
+    ld = C if ld is None else ld
+    return t.view(B, H, W, ld)[..., :C].permute(0, 3, 1, 2).float().cpu()
+
+
+def pack_bf(w):
+    N, C = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    n = lib().nd_conv_bf16_weight_elems(N, C, k)
+    assert n > 0
+    out = torch.full((n,), float('nan'), dtype=BF, device=DEV)
+    wd = w.contiguous().to(DEV)
+    _hip.check(lib().nd_repack_conv_weight_bf16(wd.data_ptr(), out.data_ptr(), N, C, k, st()))
+    return out
+
+
+@pytest.mark.parametrize('N,C,k', [(96, 64, 3), (40, 72, 3), (33, 200, 1), (128, 8, 3)])
+def test_repack_conv_weight_bf16(N, C, k):
+    w = rnd(N, C, k, k, seed=1) if k == 3 else rnd(N, C, seed=1)
+    packed = pack_bf(w).cpu()
+    taps = k * k
+    nt32 = (N + 31) // 32
+    nc = ((C + 63) // 64 + 1) & ~1
+    assert packed.numel() == (nc + 1) * nt32 * taps * 4 * 512
+    p = packed.view(nc + 1, nt32, taps, 4, 64, 8).float()
+    wq = q(w).reshape(N, C, taps)
+    full = torch.zeros(nt32 * 32, (nc + 1) * 64, taps)
+    full[:N, :C] = wq
+    # element [c64][nt][tap][ks][lane][j] = w[nt*32 + (lane&31)][c64*64 + ks*16 + (lane>>5)*8 + j][tap]
+    lane = torch.arange(64)
+    for c64 in (0, nc - 1, nc):
+        for ks in range(4):
+            for j in (0, 3, 7):
+                c = c64 * 64 + ks * 16 + (lane >> 5) * 8 + j
+                for nt in (0, nt32 - 1):
+                    n = nt * 32 + (lane & 31)
+                    for tap in (0, taps - 1):
+                        assert torch.equal(p[c64, nt, tap, ks, :, j], full[n, c, tap])
+    assert not torch.isnan(p).any()
+
+
+CONV_CASES = [  # B, Cin, Cout, H, W
+    (2, 64, 96, 16, 16), (3, 40, 72, 12, 20), (8, 128, 128, 8, 8), (1, 64, 64, 64, 64), (2, 192, 40, 7, 7),
+    (1, 8, 64, 32, 32),
+]
+
+
+def _tol_bf16(ref):
+    return 2.0 ** -8 * ref.abs() + 2e-3 * ref.abs().max().clamp(min=1.0)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', CONV_CASES)
+@pytest.mark.parametrize('ksize', [3, 1])
+def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, ksize, ksize, seed=2, scale=0.05)
+    b = rnd(Cout, seed=3)
+    ref = F.conv2d(q(x).double(), q(w).double(), b.double(), padding=ksize // 2).float()
+    xd, wd, bd = nhwc_bf(x), pack_bf(w if ksize == 3 else w[:, :, 0, 0]), b.to(DEV)
+    ran = 0
+    for v in list(range(lib().nd_conv_bf16_num_variants())) + [-1]:
+        for f32out in (False, True):
+            out = torch.full((B * H * W * Cout,), float('nan'), dtype=torch.float32 if f32out else BF, device=DEV)
+            rc = lib().nd_conv_bf16_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                         out.data_ptr(), Cout, B, H, W, Cout, ksize, _hip.CONV_OUT_F32 if f32out else 0,
+                                         v, st())
+            if rc != 0:
+                assert v >= 0 and 'no tile variant fits' in _hip.last_error(), (v, _hip.last_error())
+                continue
+            ran += 1
+            got = from_nhwc(out, B, H, W, Cout)
+            err = (got - ref).abs()
+            if f32out:      # exact bf16 products, fp32 accumulation: only the summation order differs
+                assert err.max().item() < 2e-4 * max(1.0, ref.abs().max().item()), (v, err.max().item())
+            else:
+                assert (err <= _tol_bf16(ref)).all(), (v, err.max().item())
+    assert ran >= 4
+
+
+def test_conv_bf16_fused_options():
+    """Two-source input (torch.cat), per-image bias, residual, nearest-2x input / residual, SiLU -- the options of the
+    fp32 kernel (model.py:474, :205, :211, :77-79)."""
+    B, C0, C1, N, H, W = 2, 64, 40, 96, 16, 16
+    xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, C1, H, W, seed=2)
+    w = rnd(N, C0 + C1, 3, 3, seed=3, scale=0.05)
+    b, rb, res = rnd(N, seed=4), rnd(B, N, seed=5), rnd(B, N, H, W, seed=6)
+    xad, xbd, wd = nhwc_bf(xa), nhwc_bf(xb), pack_bf(w)
+    bd, rbd, resd = b.to(DEV), rb.to(DEV), nhwc_bf(res)
+    ref = F.conv2d(torch.cat([q(xa), q(xb)], 1).double(), q(w).double(), b.double(), padding=1) + rb.double()[:, :, None, None] \
+        + q(res).double()
+    for v in (0, 4, 7, -1):
+        out = torch.empty(B * H * W * N, dtype=BF, device=DEV)
+        _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
+                                           rbd.data_ptr(), N, resd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, 0, v, st()))
+        err = (from_nhwc(out, B, H, W, N) - ref.float()).abs()
+        assert (err <= _tol_bf16(ref.float())).all(), (v, err.max().item())
+    # SiLU on the output; 1x1 with a strided output row (ldo > N) and fp32 output
+    w1 = rnd(N, C0, seed=7, scale=0.05)
+    wd1 = pack_bf(w1)
+    ref1 = F.silu(F.conv2d(q(xa).double(), q(w1).double()[:, :, None, None], b.double())).float()
+    out = torch.zeros(B * H * W * (N + 8), dtype=torch.float32, device=DEV)
+    _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd1.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                       out.data_ptr(), N + 8, B, H, W, N, 1, _hip.CONV_SILU_OUT | _hip.CONV_OUT_F32, -1, st()))
+    assert (from_nhwc(out, B, H, W, N, N + 8) - ref1).abs().max().item() < 2e-4
+    assert not out.view(B, H, W, N + 8)[..., N:].any()
+    # nearest-2x upsampled input and residual
+    xs, rs = rnd(B, C0, H // 2, W // 2, seed=8), rnd(B, N, H // 2, W // 2, seed=9)
+    w3 = rnd(N, C0, 3, 3, seed=10, scale=0.05)
+    ref_up = F.conv2d(F.interpolate(q(xs), scale_factor=2.0, mode='nearest').double(), q(w3).double(), b.double(), padding=1)
+    xsd, rsd, wd3 = nhwc_bf(xs), nhwc_bf(rs), pack_bf(w3)
+    out = torch.empty(B * H * W * N, dtype=BF, device=DEV)
+    _hip.check(lib().nd_conv_bf16_nhwc(xsd.data_ptr(), C0, C0, None, 0, 0, wd3.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                       out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_IN_UP2X, -1, st()))
+    err = (from_nhwc(out, B, H, W, N) - ref_up.float()).abs()
+    assert (err <= _tol_bf16(ref_up.float())).all()
+    ref_r = F.conv2d(q(xa).double(), q(w3).double(), b.double(), padding=1) + F.interpolate(q(rs), scale_factor=2.0, mode='nearest').double()
+    _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd3.data_ptr(), bd.data_ptr(), None, 0,
+                                       rsd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_RES_UP2X, -1, st()))
+    err = (from_nhwc(out, B, H, W, N) - ref_r.float()).abs()
+    assert (err <= _tol_bf16(ref_r.float())).all()
+
+
+def test_conv_bf16_long_k_full_size_layer():
+    """A full-size layer of the 128x128 preset (two-source 512+256 -> 256 at 64x64, B=2): long contraction (K = 6912),
+    every variant that fits gives the same result as the cost model's pick to within output rounding."""
+    B, C0, C1, N, H, W = 2, 512, 256, 256, 64, 64
+    xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, C1, H, W, seed=2)
+    w = rnd(N, C0 + C1, 3, 3, seed=3, scale=0.02)
+    b = rnd(N, seed=4)
+    xad, xbd, wd, bd = nhwc_bf(xa), nhwc_bf(xb), pack_bf(w), b.to(DEV)
+    ref = F.conv2d(torch.cat([q(xa), q(xb)], 1), q(w), b, padding=1)       # fp32 CPU conv on the same bf16 operands
+    outs = []
+    for v in range(lib().nd_conv_bf16_num_variants()):
+        out = torch.empty(B * H * W * N, dtype=torch.float32, device=DEV)
+        rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                     None, 0, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_OUT_F32, v, st())
+        if rc == 0:
+            outs.append((v, from_nhwc(out, B, H, W, N)))
+    assert len(outs) >= 6
+    for v, o in outs:
+        assert (o - ref).abs().max().item() < 1e-3 * ref.abs().max().item(), v
+
+
+def gn_stats(xd, C0, x1d, C1, B, HW, dtype):
+    stats = torch.full((B * 64,), float('nan'), dtype=torch.float64, device=DEV)
+    ws = torch.zeros((lib().nd_groupnorm_stats_workspace_bytes(B, HW, C0 + C1, 32, dtype) + 7) // 8, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_nhwc(xd.data_ptr(), C0, C0, None if x1d is None else x1d.data_ptr(), C1, C1, None, 0,
+                                             stats.data_ptr(), ws.data_ptr(), B, HW, 32, dtype, st()))
+    return stats
+
+
+@pytest.mark.parametrize('B,C0,C1,H,W', [(2, 64, 0, 16, 16), (3, 192, 64, 8, 8), (2, 256, 0, 64, 64), (1, 1024, 1024, 8, 8)])
+@pytest.mark.parametrize('mode', ['silu', 'adagn', 'pool'])
+def test_groupnorm_bf16(B, C0, C1, H, W, mode):
+    C = C0 + C1
+    xa = rnd(B, C0, H, W, seed=1) * 2 + 0.5
+    xb = rnd(B, C1, H, W, seed=2) if C1 else None
+    x = q(torch.cat([xa, xb], 1) if C1 else xa)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    scale, shift = 0.3 * rnd(B, C, seed=5), 0.3 * rnd(B, C, seed=6)
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
+    if mode == 'adagn':
+        ref = ref * (1 + scale.double()[:, :, None, None]) + shift.double()[:, :, None, None]
+    ref = F.silu(ref)
+    if mode == 'pool':
+        ref = F.avg_pool2d(ref, 2, 2)
+    xad, xbd = nhwc_bf(xa), (nhwc_bf(xb) if C1 else None)
+    stats = gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16)
+    assert torch.equal(stats, gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16))          # reproducible bits
+    s = stats.cpu().view(B, 32, 2)
+    xg = x.double().view(B, 32, -1)
+    assert torch.allclose(s[..., 0], xg.sum(-1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(s[..., 1], (xg * xg).sum(-1), rtol=1e-12, atol=1e-9)
+    Ho, Wo = (H // 2, W // 2) if mode == 'pool' else (H, W)
+    out = torch.empty(B * Ho * Wo * C, dtype=BF, device=DEV)
+    p = lambda t: None if t is None else t.data_ptr()
+    sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, None, 0, stats.data_ptr(), gd.data_ptr(),
+                                             bd.data_ptr(), p(sc), p(sh), C, out.data_ptr(), C, B, H, W, 32, 1e-5,
+                                             _hip.GN_SILU | (_hip.GN_POOL2 if mode == 'pool' else 0), _hip.DT_BF16, st()))
+    got = from_nhwc(out, B, Ho, Wo, C)
+    assert ((got - ref.float()).abs() <= 2.0 ** -8 * ref.float().abs() + 1e-4).all()
+
+
+@pytest.mark.parametrize('B,T,nh,hd,split', [(2, 64, 2, 64, True), (1, 1024, 4, 64, True), (2, 256, 3, 64, False),
+                                             (3, 196, 2, 32, True), (2, 49, 4, 64, True), (1, 1024, 4, 128, True),
+                                             (1, 256, 4, 192, True), (2, 64, 4, 256, True), (1, 64, 2, 16, False)])
+def test_attention_bf16(B, T, nh, hd, split):
+    C = nh * hd
+    qkv = rnd(B, T, 3 * C, seed=1)
+    qkv[0, T // 2, :] *= 3.0            # a spiky token: exercises the online-softmax rescale
+    qq = q(qkv)
+    if split:
+        Q, K, V = qq.view(B, T, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        offs = (0, C, 2 * C, hd)
+    else:
+        Q, K, V = qq.view(B, T, nh, 3, hd).permute(3, 0, 2, 1, 4)
+        offs = (0, hd, 2 * hd, 3 * hd)
+    scale = hd ** -0.5
+    wgt = torch.softmax(Q.double() @ K.double().transpose(-1, -2) * scale, -1)
+    ref = (wgt @ V.double()).permute(0, 2, 1, 3).reshape(B, T, C).float()
+    qd = qkv.to(BF).contiguous().to(DEV)
+    out = torch.full((B * T * C,), float('nan'), dtype=BF, device=DEV)
+    _hip.check(lib().nd_attention_bf16_nhwc(qd.data_ptr(), 3 * C, out.data_ptr(), C, B, T, nh, hd, offs[0], offs[1], offs[2],
+                                            offs[3], scale, st()))
+    got = out.view(B, T, C).float().cpu()
+    err = (got - ref).abs().max().item()
+    # probabilities and the output are rounded to bf16 (2^-9 relative each); the spiky token makes outputs of magnitude 3-4
+    assert err < 2.0 ** -7 * max(1.0, ref.abs().max().item()) + 5e-3, (err, ref.abs().max().item())
+    assert ((got - ref) ** 2).mean().sqrt().item() < 3e-3
+
+
+def test_avgpool_and_input_cast_bf16():
+    B, C, H, W = 2, 64, 8, 12
+    x = rnd(B, C, H, W, seed=1)
+    xd = nhwc_bf(x)
+    dn = torch.empty(B * (H // 2) * (W // 2) * C, dtype=BF, device=DEV)
+    _hip.check(lib().nd_avgpool2x_nhwc(xd.data_ptr(), C, dn.data_ptr(), C, B, H, W, C, _hip.DT_BF16, st()))
+    ref = F.avg_pool2d(q(x).double(), 2, 2).float()
+    assert torch.equal(from_nhwc(dn, B, H // 2, W // 2, C), q(ref))
+    # bf16 tensors through the pure-movement kernels as fp32 words of C/2 channels
+    up = torch.empty(B * 4 * H * W * C, dtype=BF, device=DEV)
+    _hip.check(lib().nd_upsample2x_nhwc(xd.data_ptr(), C // 2, up.data_ptr(), C // 2, B, H, W, C // 2, st()))
+    assert torch.equal(from_nhwc(up, B, 2 * H, 2 * W, C), F.interpolate(q(x), scale_factor=2.0, mode='nearest'))
+    # fp32 NHWC4 image -> bf16 NHWC8 (3 channels kept, 5 zero)
+    img = torch.randn(5 * 7, 4, device=DEV)
+    o = torch.full((5 * 7 * 8,), float('nan'), dtype=BF, device=DEV)
+    _hip.check(lib().nd_f32_to_bf16_rows(img.data_ptr(), 4, o.data_ptr(), 8, 3, 5 * 7, st()))
+    ov = o.view(35, 8)
+    assert torch.equal(ov[:, :3], img[:, :3].to(BF)) and not ov[:, 3:].any()
+
+
+# ---------------------------------------------------------------------------------------------------- model level
+def build(cfg, seed=1234, dtype='bf16', **kw):
+    m = DiffusionModel(**cfg)
+    m.load_state_dict(UO.synth_state_dict(cfg, seed=seed, **kw), strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def _errs(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    d = got - ref
+    return float(np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean())), float(np.abs(d).max() / np.abs(ref).max())
+
+
+@pytest.mark.parametrize('name', sorted(n for n in TINY_CFGS if n != 'odd_sizes') + ['odd_sizes'])
+def test_tiny_forward_bf16_vs_fp32_reference_golden(golden_dir, name):
+    """bf16 forward vs the REFERENCE's fp32 output (tests/golden) -- every code path of the four tiny configurations,
+    with the per-block intermediates compared too so that an error is attributed to a block."""
+    g = np.load(os.path.join(golden_dir, 'fwd_{}.npz'.format(name)))
+    m = build(TINY_CFGS[name])
+    y = torch.from_numpy(g['y']).to(DEV) if 'y' in g.files else None
+    out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV), y).cpu().numpy()
+    rms, mx = _errs(out, g['out'])
+    print('bf16 forward {}: rel rms {:.2e}, max/absmax {:.2e}'.format(name, rms, mx))
+    assert rms < 3.5e-2 and mx < 8e-2, (rms, mx)
+    B = g['x'].shape[0]
+    plan = m._plan(B)
+    assert plan.bf16
+    got = plan.run_with_taps()
+    worst = {}
+    for k in (k[4:] for k in g.files if k.startswith('tap/')):
+        worst[k] = _errs(got[k].cpu().numpy(), g['tap/' + k])[0]
+    bad = {k: v for k, v in worst.items() if not v < 4e-2}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('pname,B', [('EMNIST', 4), ('OPENAI_64', 2), ('OPENAI_128', 1), ('OPENAI_256', 1)])
+def test_preset_forward_bf16_vs_fp32(pname, B):
+    """All four presets: bf16 forward against the fp32 HIP forward of the same weights (itself pinned to the reference
+    by the fp32 tests).  Tolerance: relative rms 3.5e-2, max 8e-2 of the output's max magnitude."""
+    margs = dict(getattr(DA, pname + '_MODEL_ARGS'))
+    m = build(margs, dtype='fp32')
+    R, C = margs['resolution'], margs['in_channels']
+    torch.manual_seed(0)
+    x = torch.randn(B, C, R, R).to(DEV)
+    t = torch.tensor([17, 250, 600, 990][:B]).to(DEV)
+    y = ((torch.arange(B) * 37) % margs['num_classes']).to(DEV) if margs.get('num_classes') else None
+    ref = m(x, t, y).cpu().numpy()
+    m.compute_dtype = 'bf16'
+    got = m(x, t, y).cpu().numpy()
+    assert np.isfinite(got).all()
+    rms, mx = _errs(got, ref)
+    print('bf16 forward preset {}: rel rms {:.2e}, max/absmax {:.2e}'.format(pname, rms, mx))
+    assert rms < 3.5e-2 and mx < 8e-2, (rms, mx)
+    again = m(x, t, y).cpu().numpy()
+    assert np.array_equal(got, again)            # deterministic (no atomics on the path)
+
+
+def test_teacher_forced_steps_bf16_vs_reference_trajectory(golden_dir):
+    """DDIM and DDPM+CFG teacher-forced steps in bf16 against the reference's fp32 trajectories: x_{t-1} within 3e-2."""
+    from tests.cases import SAMPLER_CASES
+    for name in ('ddim_eta0_li', 'ddpm_cfg', 'ddpm_learned'):
+        case = SAMPLER_CASES[name]
+        g = np.load(os.path.join(golden_dir, 'sampler_{}.npz'.format(name)))
+        cfg = dict(TINY_CFGS[case['cfg']])
+        cfg['out_channels'] = cfg['in_channels'] * 2
+        m = build(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+        d = Diffusion(m, 1000, case['S'], case['var'], 'simple', beta_schedule=case['sched'],
+                      guidance_method=case.get('guidance'), guidance_strength=case.get('w'), use_ddim=case['ddim'],
+                      ddim_eta=case.get('eta'), device=torch.device(DEV))
+        y = torch.from_numpy(g['y']).to(DEV) if 'y' in g.files else None
+        noises = torch.from_numpy(g['noises'])
+        traj = g['traj']
+        S = case['S']
+        x = torch.from_numpy(g['xT'])
+        worst = 0.0
+        for i, t in enumerate(reversed(range(S))):
+            got = d.denoise(x=x, kwargs={'y': y} if y is not None else {}, batch_size=x.shape[0], steps_to_do=1, first_index=t,
+                            progress=False, noise=noises).cpu().numpy()
+            worst = max(worst, float(np.abs(got - traj[i]).max()))
+            x = torch.from_numpy(traj[i])
+        print('bf16 teacher-forced {}: max |x_(t-1) - reference| {:.2e}'.format(name, worst))
+        assert worst < 3e-2, (name, worst)
+
+
+def test_config4_workload_bf16_ddpm_cfg_128():
+    """BASELINE configs[3] in bf16: 128x128 preset, num_classes=1001, DDPM, CFG 0.8 -- teacher-forced steps at B=1 against
+    the fp32 ORACLE (CPU restatement of the reference) with injected noise, graph replay == eager, deterministic."""
+    margs = dict(DA.OPENAI_128_MODEL_ARGS)
+    margs['num_classes'] = 1001
+    m = build(margs)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    kw = dict(beta_schedule='linear', use_ddim=False, guidance_method='classifier_free', guidance_strength=0.8)
+    d = Diffusion(m, 1000, 1000, 'learned_interpolation', 'hybrid', device=torch.device(DEV), **kw)
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, margs, xx, tt, yy), DO.Schedule(1000, 1000, 'linear'),
+                          'learned_interpolation', use_ddim=False, guidance_method='classifier_free', guidance_strength=0.8)
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 128, 128)
+    y = torch.tensor([417])
+    for t in (999, 0):
+        nz = torch.randn(1, 3, 128, 128)
+        noises = torch.zeros(t + 1, 1, 3, 128, 128)
+        noises[t] = nz
+        got = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=1, steps_to_do=1, first_index=t, progress=False,
+                        noise=noises).cpu()
+        ref, _ = so.ddpm_step(x, t, y, nz)
+        err = (got - ref).abs().max().item()
+        print('bf16 config[3] teacher-forced step t={}: max err {:.2e}'.format(t, err))
+        assert err < 3e-2, (t, err)
+        del noises
+    B = 8
+    xb = torch.randn(B, 3, 128, 128)
+    yb = (torch.arange(B) * 37) % 1000 + 1
+    d.seed = 123
+    a = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    b = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    d.use_graph = False
+    c = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)

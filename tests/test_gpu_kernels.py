@@ -45,6 +45,19 @@ def pack_w(w):      # [N,C,k,k] or [N,C] cpu -> MFMA-fragment order on the devic
     return out
 
 
+def gn_stats(x0, C0, ld0, x1, C1, ld1, add, ld_add, B, HW, dtype=_hip.DT_F32, G=32):
+    """nd_groupnorm_stats_nhwc with a freshly allocated workspace; the statistics buffer starts as NaN (the kernel must
+    write every entry) and the tickets must be left zero."""
+    stats = torch.full((B * G * 2,), float('nan'), dtype=torch.float64, device=DEV)
+    nbytes = lib().nd_groupnorm_stats_workspace_bytes(B, HW, C0 + C1, G, dtype)
+    assert nbytes > 0
+    ws = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_nhwc(x0, C0, ld0, x1, C1, ld1, add, ld_add, stats.data_ptr(), ws.data_ptr(), B, HW,
+                                             G, dtype, st()))
+    assert not ws.view(torch.int32)[:B].any(), 'tickets not reset'
+    return stats
+
+
 def test_arch_and_version():
     assert lib().nd_device_arch().decode().startswith('gfx950')
     _hip.require_gfx950(0)
@@ -219,9 +232,7 @@ def test_conv_with_fused_groupnorm(silu):
     w3, w1, b = rnd(Cout, C, 3, 3, seed=7, scale=0.05), rnd(Cout, C, seed=8, scale=0.05), rnd(Cout, seed=9)
     ref3, ref1 = F.conv2d(h, w3, b, padding=1), F.conv2d(h, w1[:, :, None, None], b)
     xad, xbd, bd = nhwc(xa), nhwc(xb), b.to(DEV)
-    stats = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
-    _hip.check(lib().nd_groupnorm_stats_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, None, 0, stats.data_ptr(), B,
-                                             H * W, 32, st()))
+    stats = gn_stats(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, None, 0, B, H * W)
     gd, btd, scd, shd = gamma.to(DEV), beta.to(DEV), scale.to(DEV), shift.to(DEV)
     cA, cB = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
     _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), gd.data_ptr(), btd.data_ptr(), scd.data_ptr(), shd.data_ptr(), C,
@@ -268,7 +279,8 @@ def test_conv_direct_stride2():
     assert (from_nhwc(out, B, 8, 8, N) - ref).abs().max().item() < 1e-4
 
 
-GN_CASES = [(2, 32, 0, 16, 16), (3, 192, 0, 8, 8), (2, 64, 32, 7, 7), (1, 768, 768, 8, 8), (2, 96, 0, 28, 28)]
+GN_CASES = [(2, 32, 0, 16, 16), (3, 192, 0, 8, 8), (2, 64, 32, 7, 7), (1, 768, 768, 8, 8), (2, 96, 0, 28, 28),
+            (2, 192, 0, 64, 64)]       # the last one spans many blocks per image: per-block partials + ticket path
 
 
 @pytest.mark.parametrize('B,C0,C1,H,W', GN_CASES)
@@ -292,11 +304,11 @@ def test_groupnorm(B, C0, C1, H, W, mode):
         ref = F.avg_pool2d(ref, 2, 2)
     xad = nhwc(xa)
     xbd = nhwc(xb) if C1 else None
-    stats = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
     addd = add.to(DEV) if mode == 'addvec' else None
     p = lambda t: None if t is None else t.data_ptr()
-    _hip.check(lib().nd_groupnorm_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(), B,
-                                             H * W, 32, st()))
+    stats = gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W)
+    # no floating-point atomics: a second launch gives the same bits
+    assert torch.equal(stats, gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W))
     sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
     Ho, Wo = (H // 2, W // 2) if mode == 'pool' else (H, W)
     out = torch.empty(B * Ho * Wo * C, device=DEV)
@@ -304,7 +316,7 @@ def test_groupnorm(B, C0, C1, H, W, mode):
     gd, bd = gamma.to(DEV), beta.to(DEV)
     _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(),
                                              gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C, out.data_ptr(), C, B, H, W, 32,
-                                             1e-5, flags, st()))
+                                             1e-5, flags, _hip.DT_F32, st()))
     # statistics themselves (float64 sums)
     s = stats.cpu().view(B, 32, 2)
     xg = xin.double().view(B, 32, -1)
@@ -379,7 +391,7 @@ def test_resample_and_layout():
     _hip.check(lib().nd_upsample2x_nhwc(xd.data_ptr(), C, up.data_ptr(), C, B, H, W, C, st()))
     assert torch.equal(from_nhwc(up, B, 2 * H, 2 * W, C), F.interpolate(x, scale_factor=2.0, mode='nearest'))
     dn = torch.empty(B * (H // 2) * (W // 2) * C, device=DEV)
-    _hip.check(lib().nd_avgpool2x_nhwc(xd.data_ptr(), C, dn.data_ptr(), C, B, H, W, C, st()))
+    _hip.check(lib().nd_avgpool2x_nhwc(xd.data_ptr(), C, dn.data_ptr(), C, B, H, W, C, _hip.DT_F32, st()))
     assert (from_nhwc(dn, B, H // 2, W // 2, C) - F.avg_pool2d(x, 2, 2)).abs().max().item() < 1e-6
     # NCHW <-> NHWC with channel padding
     x3 = rnd(B, 3, H, W, seed=2).to(DEV)
@@ -572,16 +584,14 @@ def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
     assert ((c[:, 1] - (g64 ** 2).sum((2, 3))).abs() / (g64 ** 2).sum((2, 3))).max().item() < 1e-5
     if Cout % 32 == 0:
         rows = mbi.value * 4
-        a = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        a = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
         _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
-        b2 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
-        _hip.check(lib().nd_groupnorm_stats_nhwc(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, b2.data_ptr(), B, H * W, 32, st()))
+        b2 = gn_stats(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, B, H * W)
         assert ((a - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
         # two-source (concatenated) form vs the statistics kernel on the concatenation [out | out]
-        a2 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+        a2 = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
         _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, ps.data_ptr(), Cout, rows, a2.data_ptr(), B, 32, st()))
-        b3 = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
-        _hip.check(lib().nd_groupnorm_stats_nhwc(out.data_ptr(), Cout, Cout, out.data_ptr(), Cout, Cout, None, 0, b3.data_ptr(), B, H * W, 32, st()))
+        b3 = gn_stats(out.data_ptr(), Cout, Cout, out.data_ptr(), Cout, Cout, None, 0, B, H * W)
         assert ((a2 - b3).abs() / b3.abs().clamp(min=1.0)).max().item() < 1e-5
     # ldo must equal N
     rc = lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,

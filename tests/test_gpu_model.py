@@ -160,9 +160,9 @@ def test_sampler_loops_vs_reference_golden(golden_dir, name):
     assert np.abs(torch.stack(tr).cpu().numpy() - traj).max() < 1e-3
     d.use_graph = True
     out_g = d.denoise(x=xT, kwargs=kwargs, batch_size=B, progress=False, noise=noises)
-    assert torch.equal(out_g, out_e) or (out_g - out_e).abs().max().item() < 1e-6
+    assert torch.equal(out_g, out_e)          # no atomics anywhere on the path: replay == eager bit for bit
     out_g2 = d.denoise(x=xT, kwargs=kwargs, batch_size=B, progress=False, noise=noises)      # cached graph
-    assert (out_g2 - out_g).abs().max().item() < 1e-6
+    assert torch.equal(out_g2, out_g)
     assert np.abs(out_g.cpu().numpy() - traj[-1]).max() < 1e-3
 
 
@@ -315,7 +315,7 @@ def test_one_captured_graph_serves_every_seed():
     c2 = d.denoise(x=xT, kwargs={'y': y}, batch_size=2, progress=False)
     d.use_graph = False
     c3 = d.denoise(x=xT, kwargs={'y': y}, batch_size=2, progress=False)
-    assert torch.equal(c1, c2) and (c1 - c3).abs().max().item() < 1e-6
+    assert torch.equal(c1, c2) and torch.equal(c1, c3)
 
 
 def test_epilogue_statistics_option_matches_default(monkeypatch):
@@ -391,7 +391,7 @@ def test_full_size_properties_config2():
                   device=DEV)
     a = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     b = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
-    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5
+    assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_config4_workload_fp32_ddpm_cfg_128():
@@ -428,7 +428,7 @@ def test_config4_workload_fp32_ddpm_cfg_128():
     b = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
     d.use_graph = False
     c = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
-    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5 and (a - c).abs().max().item() < 1e-5
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
     # row 0 of the batched run = the same row run alone (nothing on the path mixes samples; Philox is keyed per element)
     d.use_graph = True
     solo = d.denoise(x=xb[:1], kwargs={'y': yb[:1].to(DEV)}, batch_size=1, steps_to_do=3, progress=False)
