@@ -30,8 +30,26 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL ne
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X dense fp32 (vector = matrix) peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide; the 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
+# BASELINE.json configs.  The default (and the line the driver records) is configs[1]; --workload config4 / config5 run
+# the bf16 configurations at their per-GPU batch on one GPU (their lines are kept under profiles/).
+WORKLOADS = {
+    'config2': dict(preset='OPENAI_64', chain=250, ddim=True, sched='cosine', batch=64, dtype='fp32', cfg=None,
+                    metric='sampled images/sec (250-step DDIM, 64x64 cond ImageNet UNet)',
+                    name='64x64 conditional ImageNet UNet (OPENAI_64 preset, 296M params), {}-step DDIM eta=0, cosine '
+                         'schedule, learned_interpolation'),
+    'config4': dict(preset='OPENAI_128', chain=1000, ddim=False, sched='linear', batch=16, dtype='bf16', cfg=0.8,
+                    metric='sampled images/sec (1000-step DDPM, classifier-free guidance, 128x128 cond ImageNet UNet, bf16)',
+                    name='128x128 conditional ImageNet UNet (OPENAI_128 preset + null class, 422M params), {}-step DDPM '
+                         'p_sample, linear schedule, learned_interpolation, classifier-free guidance w=0.8 (2B forwards '
+                         'per step)'),
+    'config5': dict(preset='OPENAI_256', chain=50, ddim=True, sched='linear', batch=16, dtype='bf16', cfg=None,
+                    metric='sampled images/sec (50-step DDIM, 256x256 UNet, bf16)',
+                    name='256x256 UNet (OPENAI_256 preset, random-init, 554M params), {}-step DDIM eta=0, linear schedule, '
+                         'learned_interpolation'),
+}
 PRESET_STEPS = 250
 PER_GPU_BATCH = 64
 
@@ -52,16 +70,21 @@ def synthetic_weights(model, seed=1234):
                 p.copy_(0.02 * n)
 
 
-def build(device, small=False):
-    from nicediffusion.default_args import OPENAI_64_MODEL_ARGS
+def build(device, wl=None):
+    from nicediffusion import default_args as DA
     from nicediffusion.model import DiffusionModel
     from nicediffusion.diffusion import Diffusion
-    margs = dict(OPENAI_64_MODEL_ARGS)
+    wl = WORKLOADS['config2'] if wl is None else wl
+    margs = dict(getattr(DA, wl['preset'] + '_MODEL_ARGS'))
+    if wl['cfg'] is not None:
+        margs['num_classes'] += 1            # classifier-free guidance adds the null class (utils.py:211-212)
     model = DiffusionModel(**margs)
     synthetic_weights(model)
     model.to(device).eval()
-    diff = Diffusion(model, original_num_steps=1000, rescaled_num_steps=PRESET_STEPS, sampling_var_type='learned_interpolation',
-                     loss_type='hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0, guidance_method=None,
+    model.compute_dtype = wl['dtype']
+    diff = Diffusion(model, original_num_steps=1000, rescaled_num_steps=wl['chain'], sampling_var_type='learned_interpolation',
+                     loss_type='hybrid', beta_schedule=wl['sched'], use_ddim=wl['ddim'], ddim_eta=0.0 if wl['ddim'] else None,
+                     guidance_method=None if wl['cfg'] is None else 'classifier_free', guidance_strength=wl['cfg'],
                      device=device)
     return margs, model, diff
 
@@ -84,102 +107,153 @@ def kernel_breakdown(model, batch, reps=2):
     return plan, acc
 
 
-def roofline_from(rows, lib):
-    """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time in one forward."""
+def _traffic_table():
+    """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/r02_pmc_shapes.json:
+    one entry per (kernel kind, variant, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
+    inside this process, so the table is regenerated by that script and looked up by the shapes actually launched."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_shapes.json')))
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_from(rows, lib, dtype='fp32', esize=4):
+    """Dominant kernel = the conv kernel instantiation with the largest total time in one forward.  `achieved` / `frac`
+    are EXECUTED matrix-pipe flops per second (the Winograd kernels execute 4/9 of the direct-convolution flops);
+    the algorithmic (direct-convolution) rate is kept under `algorithmic_equivalent`."""
     import ctypes
+    conv_fns = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc')
+    peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
+
+    def executed(r):
+        return r['flops'] * (4.0 / 9.0 if r['variant'] and r['variant'][0] == 'wino' else 1.0)
     groups = {}
     for r in rows:
-        if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc'):
+        if r['fn'] not in conv_fns or not r.get('variant'):
             continue
-        key = (r['variant'], r['ksize'])
-        g = groups.setdefault(key, dict(ms=0.0, flops=0, launches=0))
+        key = (tuple(r['variant']), r['ksize'])
+        g = groups.setdefault(key, dict(ms=0.0, flops=0, exec=0.0, launches=0, rows=[]))
         g['ms'] += r['ms']
         g['flops'] += r['flops']
+        g['exec'] += executed(r)
         g['launches'] += 1
+        g['rows'].append(r)
     key, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
     (kind, var), ksize = key
+    bm, bn, nt, nsub, apf = (ctypes.c_int() for _ in range(5))
     if kind == 'wino':
-        bm, bn, nt, nsub, apf = (ctypes.c_int() for _ in range(5))
         lib.nd_conv_winograd_variant_info(var, *(ctypes.byref(v) for v in (bm, bn, nt, nsub, apf)))
         kname = '{} (Winograd F(2x2,3x3) on fp32 MFMA; {} px x {} ch per block, {} threads)'.format(
             lib.nd_conv_winograd_variant_name(var).decode(), bm.value, bn.value, nt.value)
-        executed = 4.0 / 9.0
+    elif kind == 'bf16':
+        lib.nd_conv_bf16_variant_info(max(var, 0), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
+        kname = 'nd::conv_bf16_kernel<{}x{} tile, {} threads, {} taps> (v_mfma_f32_32x32x16_bf16)'.format(
+            bm.value, bn.value, nt.value, ksize * ksize)
     else:
-        bm, bn, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.nd_conv_variant_info(var, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         kname = 'nd::conv_mfma_kernel<{}x{} tile, {} threads, {} taps>'.format(bm.value, bn.value, nt.value, ksize * ksize)
-        executed = 1.0
+    # HBM traffic of this kernel over the forward: counter bytes of every shape it ran on / algorithmic bytes
     traffic = None
-    try:      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
-        for name, rec in pmc.items():
-            if isinstance(rec, dict) and kname.startswith(name) and 'hbm_bytes' in rec:
-                traffic = {'hbm_bytes_per_launch': rec['hbm_bytes'], 'algorithmic_bytes': rec['algorithmic_bytes'],
-                           'shape': rec['shape'], 'source': 'profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)'}
-    except (OSError, ValueError):
-        pass
-    achieved = g['flops'] / (g['ms'] * 1e-3) / 1e12
+    tab = _traffic_table()
+    if tab:
+        hb = ab = 0.0
+        missing = 0
+        for r in g['rows']:
+            NI, H, W, Cin, N = r['shape']
+            rec = tab.get('{}:{}:{}:{}:{}:{}:{}'.format(kind, var, NI, H, W, Cin, N))
+            alg = esize * (NI * H * W * (Cin + N) + ksize * ksize * Cin * N)
+            if rec is None:
+                missing += 1
+                continue
+            hb += rec['hbm_bytes']
+            ab += alg
+        if ab > 0:
+            traffic = {'hbm_bytes_per_launch': hb / max(1, g['launches'] - missing), 'algorithmic_bytes_per_launch':
+                       ab / max(1, g['launches'] - missing), 'ratio': round(hb / ab, 3), 'shapes_missing': missing,
+                       'source': 'profiles/r02_pmc_shapes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, keyed '
+                                 'by the shapes launched)'}
+    sec = g['ms'] * 1e-3
+    achieved = g['exec'] / sec / 1e12
     total_ms = sum(r['ms'] for r in rows)
     conv_ms = sum(v['ms'] for v in groups.values())
     conv_fl = sum(v['flops'] for v in groups.values())
+    conv_ex = sum(v['exec'] for v in groups.values())
     return {
-        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_TFLOPS, 4), 'traffic': traffic,
+        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4), 'traffic': traffic,
         'kernel': kname,
-        'note': 'achieved = algorithmic (direct-convolution) flops / time; the Winograd kernel executes 4/9 of them '
-                'on the matrix pipe, so frac can exceed 1' if kind == 'wino' else 'achieved = algorithmic flops / time',
-        'mfma_pipe_frac': round(achieved * executed / PEAK_F32_TFLOPS, 4),
+        'note': 'achieved = flops EXECUTED on the matrix pipe / time (Winograd F(2x2,3x3): 4/9 of the direct-convolution '
+                'flops); algorithmic_equivalent = direct-convolution flops / time',
+        'algorithmic_equivalent': round(g['flops'] / sec / 1e12, 2),
         'launches_per_forward': g['launches'], 'avg_launch_ms': round(g['ms'] / g['launches'], 4),
         'flops_per_launch_avg': g['flops'] / g['launches'],
         'share_of_forward_time': round(g['ms'] / total_ms, 4),
-        'all_mfma_conv': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), 'share_of_forward_time':
-                          round(conv_ms / total_ms, 4)},
-    }, total_ms
+        'all_mfma_conv': {'executed_tflops': round(conv_ex / (conv_ms * 1e-3) / 1e12, 2),
+                          'frac_of_peak': round(conv_ex / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                          'algorithmic_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                          'share_of_forward_time': round(conv_ms / total_ms, 4)},
+    }, total_ms, conv_ex
 
 
 def class_breakdown(rows):
     out = {}
     for r in rows:
-        k = r['label'].split('.')[0] if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc') else r['label']
+        k = r['label'].split('.')[0] if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc') else r['label']
         if r['fn'].startswith('nd_groupnorm'):
             k = 'groupnorm_' + r['fn'].split('_')[2]
         out[k] = out.get(k, 0.0) + r['ms']
     return {k: round(v, 3) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
 
 
-def cpu_baseline(model, diff, margs, batch=8, steps=2):
+def cpu_baseline(model, margs, wl, batch=None, steps=2):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned against it in tests/) on this box's
-    host cores: `steps` DDIM steps at B=`batch` of the same preset, extrapolated to the 250-step chain."""
+    host cores: `steps` sampler steps (UNet forward(s) + update) of the same workload at a small batch, extrapolated to
+    the whole chain."""
     from oracle import unet_oracle as UO, diffusion_oracle as DO
+    R = margs['resolution']
+    if batch is None:
+        batch = 8 if R <= 64 else (2 if R <= 128 else 1)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    so = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(sd, margs, a, b, c), DO.Schedule(1000, PRESET_STEPS, 'cosine'),
-                          'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    so = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(sd, margs, a, b, c), DO.Schedule(1000, wl['chain'], wl['sched']),
+                          'learned_interpolation', use_ddim=wl['ddim'], ddim_eta=0.0 if wl['ddim'] else None,
+                          guidance_method=None if wl['cfg'] is None else 'classifier_free', guidance_strength=wl['cfg'])
     torch.manual_seed(0)
-    x = torch.randn(batch, 3, 64, 64)
-    y = (torch.arange(batch) * 37) % 1000
-    t = PRESET_STEPS - 1
-    x, _ = so.ddim_step(x, t, y)          # warm-up (thread pool, oneDNN primitive cache)
+    x = torch.randn(batch, 3, R, R)
+    y = (torch.arange(batch) * 37) % 1000 + (1 if wl['cfg'] is not None else 0)
+    step = so.ddim_step if wl['ddim'] else so.ddpm_step
+    t = wl['chain'] - 1
+    x, _ = step(x, t, y)          # warm-up (thread pool, oneDNN primitive cache)
     t0 = time.perf_counter()
     for i in range(steps):
-        x, _ = so.ddim_step(x, t - 1 - i, y)
+        x, _ = step(x, t - 1 - i, y)
     dt = (time.perf_counter() - t0) / steps
-    return {'value': round(batch / (dt * PRESET_STEPS), 6), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+    return {'value': round(batch / (dt * wl['chain']), 6), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port', 'host_cpus': os.cpu_count(),
-            'sample': '{} DDIM steps (UNet forward + update) at batch {} of the same 64x64 preset on the host cores, '
-                      '{:.2f} s/step, extrapolated x{} steps'.format(steps, batch, dt, PRESET_STEPS)}
+            'sample': '{} sampler steps (UNet forward{} + update) at batch {} of the same {}x{} preset on the host cores, '
+                      '{:.2f} s/step, extrapolated x{} steps'.format(steps, 's (2 per step, CFG)' if wl['cfg'] is not None else '',
+                                                                     batch, R, R, dt, wl['chain'])}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1, help='timed passes (each = one 250-step DDIM chain per GPU)')
+    ap.add_argument('--steps', type=int, default=1, help='timed passes (each = one whole sampling chain per GPU)')
     ap.add_argument('--warmup', type=int, default=1, help='untimed passes')
-    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='images per GPU')
-    ap.add_argument('--chain', type=int, default=PRESET_STEPS, help='(debug) DDIM steps per pass; the metric needs 250')
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS),
+                    help='BASELINE.json configuration: config2 = configs[1] (the headline metric, default); config4 / config5 = '
+                         'configs[3] / [4], bf16, at their per-GPU batch')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
+    ap.add_argument('--chain', type=int, default=None, help='(debug) sampler steps per pass; the metric needs the full chain')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='(debug/profiling) launch every step eagerly instead of hipGraph replay')
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    full_chain = wl['chain']
+    if args.chain is None:
+        args.chain = full_chain
+    if args.batch is None:
+        args.batch = wl['batch']
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -219,21 +293,25 @@ def main():
             def denoise(self, x, kwargs, batch_size, steps_to_do, progress):
                 assert x.shape[0] == batch_size == kwargs['y'].shape[0]
                 return x + 1
-        margs, model, diff = None, None, _StubDiffusion()
+        margs, model, diff = dict(resolution=64), None, _StubDiffusion()
     else:
-        margs, model, diff = build(device)
+        margs, model, diff = build(device, wl)
+        diff.seed = 1234                       # DDPM: in-kernel Philox noise, same seed on every rank (rows keyed globally)
     if args.no_graph:
         diff.use_graph = False
     B = args.batch
     Bg = B * world
+    R = margs['resolution']
     # global batch generated identically on every rank, then sliced (an N-GPU run is comparable row by row)
     torch.manual_seed(0)
-    x_global = torch.randn(Bg, 3, 64, 64)
-    y_global = (torch.arange(Bg) * 37) % 1000
+    x_global = torch.randn(Bg, 3, R, R)
+    y_global = (torch.arange(Bg) * 37) % 1000 + (1 if wl['cfg'] is not None else 0)     # CFG: label 0 is the null class
     from nicediffusion.parallel import shard_slice, all_gather_rows
     sl = shard_slice(Bg, rank, world)
     x_local = x_global[sl].to(device)
     y_local = y_global[sl].to(device)
+    if not stub:
+        diff.first_row = sl.start
 
     def one_pass():
         out = diff.denoise(x=x_local, kwargs={'y': y_local}, batch_size=B, steps_to_do=args.chain, progress=False)
@@ -265,31 +343,42 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = Bg * args.steps / dt * (args.chain / PRESET_STEPS)   # == Bg*steps/dt for the real 250-step chain
+        value = Bg * args.steps / dt * (args.chain / full_chain)   # == Bg*steps/dt for the real full-length chain
+        fwd_per_step = 2 if wl['cfg'] is not None else 1
         line = {
-            'metric': 'sampled images/sec (250-step DDIM, 64x64 cond ImageNet UNet)', 'value': round(value, 4),
+            'metric': wl['metric'], 'value': round(value, 4),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (random-init weights, randn x_T, labels (arange*37)%1000)',
-            'config': {'workload': '64x64 conditional ImageNet UNet (OPENAI_64 preset, 296M params), {}-step DDIM '
-                                   'eta=0, cosine schedule, learned_interpolation'.format(args.chain),
-                       'per_gpu_batch': B, 'global_batch': Bg, 'ddim_steps_per_pass': args.chain,
+            'dtype': 'f32' if wl['dtype'] == 'fp32' else 'bf16',
+            'data': 'synthetic (random-init weights, randn x_T, labels (arange*37)%1000)',
+            'config': {'workload': wl['name'].format(args.chain), 'baseline_config': args.workload,
+                       'per_gpu_batch': B, 'global_batch': Bg, 'sampler_steps_per_pass': args.chain,
+                       'unet_forwards_per_sampler_step': fwd_per_step * B,
                        'parallelism': ('batch-shard x{} + all-gather'.format(world) if world > 1 else 'single GPU') +
                                       ('' if backend == 'nccl' else ' [REHEARSAL backend={}{}: not a measurement]'.format(
                                           backend, ', stub denoiser on CPU' if stub else '')),
                        'loop': 'hipGraph replay' if diff.use_graph else 'eager'},
-            'ms_per_unet_forward_plus_update': round(ms_per_step / args.chain, 3),
+            'ms_per_sampler_step': round(ms_per_step / args.chain, 3),
         }
+        if wl['dtype'] == 'bf16':
+            line['config']['precision'] = ('bf16 activations and weights in HBM, fp32 accumulation, fp32 GroupNorm statistics, '
+                                           'fp32 embedding MLP and sampler state (tolerance vs the fp32 reference: DESIGN.md)')
         if not args.no_breakdown:
-            plan, rows = kernel_breakdown(model, B)
-            roof, fwd_ms = roofline_from(rows, plan.lib)
+            NI = fwd_per_step * B
+            plan, rows = kernel_breakdown(model, NI)
+            roof, fwd_ms, conv_exec = roofline_from(rows, plan.lib, wl['dtype'], 2 if wl['dtype'] == 'bf16' else 4)
             line['roofline'] = roof
-            line['forward'] = {'eager_sum_of_kernels_ms': round(fwd_ms, 3), 'algorithmic_tflop': round(plan.flops / 1e12, 4),
-                               'tflops': round(plan.flops / (fwd_ms * 1e-3) / 1e12, 2),
-                               'frac_of_f32_peak': round(plan.flops / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4),
+            peak = PEAK_BF16_TFLOPS if wl['dtype'] == 'bf16' else PEAK_F32_TFLOPS
+            other_fl = plan.flops - sum(r['flops'] for r in rows if r.get('variant') and r['fn'] != 'nd_attention_nhwc')
+            exec_fl = conv_exec + max(other_fl, 0)      # attention / linears execute their algorithmic flops
+            line['forward'] = {'images': NI, 'eager_sum_of_kernels_ms': round(fwd_ms, 3),
+                               'algorithmic_tflop': round(plan.flops / 1e12, 4),
+                               'algorithmic_tflops': round(plan.flops / (fwd_ms * 1e-3) / 1e12, 2),
+                               'executed_tflop': round(exec_fl / 1e12, 4),
+                               'executed_frac_of_matrix_peak': round(exec_fl / (fwd_ms * 1e-3) / 1e12 / peak, 4),
                                'launches': len(rows), 'ms_by_class': class_breakdown(rows)}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(model, diff, margs)
+            line['cpu_baseline'] = cpu_baseline(model, margs, wl)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()              # the other ranks wait here while rank 0 measures the per-kernel breakdown

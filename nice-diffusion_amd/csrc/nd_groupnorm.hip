@@ -12,12 +12,13 @@
 // rate is far above what the stream needs, and E[x^2]-E[x]^2 in float64 has no cancellation problem for fp32 data).
 // Everything after the per-thread sums runs in a FIXED order, so the statistics are bitwise reproducible from run
 // to run: the pixel rows of a block are folded through LDS in row order, the channels of a group in channel order,
-// each block stores its per-(image, group) partial, and the block that draws the last ticket of its image (agent-scope
-// release / acquire around one relaxed atomic) adds the partials in block order and writes the statistics.  No
-// floating-point atomics anywhere.  Pass 2 (apply) folds mean/rstd/gamma/beta and the AdaGN scale/shift into one FMA
+// each block stores its per-(image, group) partial (agent-scope stores), and the block that draws the last ticket of its
+// image (one relaxed integer atomic) adds the partials in block order and writes the statistics.  No floating-point
+// atomics anywhere.  Pass 2 (apply) folds mean/rstd/gamma/beta and the AdaGN scale/shift into one FMA
 // per element (coefficients staged in LDS per block), applies SiLU and optionally the 2x2 average pool, and writes
 // 16 bytes per lane.
 #include "nd_common.h"
+#include <stdlib.h>
 
 namespace nd {
 
@@ -30,22 +31,26 @@ typedef __bf16 gn_bf16x8 __attribute__((ext_vector_type(8)));
 template <typename T> struct GnVec;
 template <> struct GnVec<float> {
     static constexpr int N = 4;
-    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    typedef f32x4 Raw;
+    __device__ static __forceinline__ Raw raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    __device__ static __forceinline__ void expand(const Raw& t, float (&v)[4]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = t[e];
     }
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) { expand(raw(p), v); }
     __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     }
 };
 template <> struct GnVec<__bf16> {
     static constexpr int N = 8;
-    __device__ static __forceinline__ void load(const __bf16* p, float (&v)[8]) {
-        const gn_bf16x8 t = *reinterpret_cast<const gn_bf16x8*>(p);
+    typedef gn_bf16x8 Raw;
+    __device__ static __forceinline__ Raw raw(const __bf16* p) { return *reinterpret_cast<const gn_bf16x8*>(p); }
+    __device__ static __forceinline__ void expand(const Raw& t, float (&v)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
     }
+    __device__ static __forceinline__ void load(const __bf16* p, float (&v)[8]) { expand(raw(p), v); }
     __device__ static __forceinline__ void store(__bf16* p, const float (&v)[8]) {
         gn_bf16x8 t;
 #pragma unroll
@@ -99,7 +104,37 @@ __global__ void __launch_bounds__(GN_NT)
             }
         }
         const size_t base = (size_t)img * HW;
-        for (int p = p0 + tp; p < p1; p += PY) {
+        // 4 pixels per trip: all their loads are issued before the first is consumed (the stream is latency-bound at one
+        // 16-byte load in flight per thread)
+        constexpr int UP = 4;
+        int p = p0 + tp;
+        for (; p + (UP - 1) * PY < p1; p += UP * PY) {
+            typename GnVec<T>::Raw raw[UP][GN_MAXQ];
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int j = 0; j < GN_MAXQ; ++j) {
+                    const int qd = tq + j * QX;
+                    if (qd < CQ) raw[u][j] = GnVec<T>::raw(gn_ptr(s, base + p + u * PY, qd * V));
+                }
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int j = 0; j < GN_MAXQ; ++j) {
+                    const int qd = tq + j * QX;
+                    if (qd < CQ) {
+                        float v[V];
+                        GnVec<T>::expand(raw[u][j], v);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const double d = (double)(v[e] + add[j][e]);
+                            sum[j][e] += d;
+                            ssq[j][e] += d * d;
+                        }
+                    }
+                }
+        }
+        for (; p < p1; p += PY) {
 #pragma unroll
             for (int j = 0; j < GN_MAXQ; ++j) {
                 const int qd = tq + j * QX;
@@ -149,35 +184,60 @@ __global__ void __launch_bounds__(GN_NT)
             a += sh[c * 2];
             b += sh[c * 2 + 1];
         }
-        double* dst = partials + (((size_t)img * nchunks + blockIdx.x) * G + tid) * 2;
-        if (nchunks == 1) dst = stats + ((size_t)img * G + tid) * 2;        // single block per image: final already
-        dst[0] = a;
-        dst[1] = b;
+        if (nchunks == 1) {                                               // single block per image: final already
+            double* dst = stats + ((size_t)img * G + tid) * 2;
+            dst[0] = a;
+            dst[1] = b;
+        } else {
+            // hand-off to the last block of the image: agent-scope (sc1, write-through) stores and loads of the partials
+            // themselves, so that no release / acquire fence -- an L2 write-back and invalidate per block, with the
+            // producing convolution's output still dirty in L2 -- is needed around the ticket
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(partials) +
+                                      (((size_t)img * nchunks + blockIdx.x) * G + tid) * 2;
+            __hip_atomic_store(dst, __double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, __double_as_longlong(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (nchunks == 1) return;
-    // publish the partial, draw a ticket; the last block of the image adds the partials in block order
+    // every partial of this block is out (vmcnt drained, then the barrier) before thread 0 draws the ticket; the block
+    // that draws the last ticket of its image adds the partials in block order
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(sh);
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(&tickets[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == nchunks - 1) ? 1 : 0;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&tickets[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
+        if (last) __hip_atomic_store(&tickets[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         *flag = last;
     }
     __syncthreads();
     if (*flag == 0) return;
-    if (tid < 2 * G) {
-        const double* src = partials + (size_t)img * nchunks * G * 2 + tid;
-        double a = 0.0;
-        for (int k = 0; k < nchunks; ++k) a += src[(size_t)k * G * 2];
-        stats[(size_t)img * G * 2 + tid] = a;
+    // value v = tid % (2G) (sum | sum of squares of a group), lane kq = tid / (2G) of KQ takes the blocks k = kq, kq + KQ, ...
+    // in order with 8 loads in flight; the KQ partial sums are then added in lane order: a fixed order all the way
+    const int NV = 2 * G;
+    const int KQ = GN_NT / NV;                    // >= 2 (G <= 128 is checked on the host; G = 32 gives 4)
+    const int vi = tid % NV, kq = tid / NV;
+    double acc = 0.0;
+    if (kq < KQ) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(partials) + (size_t)img * nchunks * NV + vi;
+        for (int k0 = kq; k0 < nchunks; k0 += 8 * KQ) {
+            unsigned long long r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * KQ;
+                r[u] = (k < nchunks) ? __hip_atomic_load(src + (size_t)k * NV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += __longlong_as_double(r[u]);       // 0ull is +0.0
+        }
+    }
+    __syncthreads();                              // everyone has read the flag word before sh is reused
+    if (kq < KQ) sh[kq * NV + vi] = acc;
+    __syncthreads();
+    if (tid < NV) {
+        double a = sh[tid];
+        for (int j = 1; j < KQ; ++j) a += sh[j * NV + tid];
+        stats[(size_t)img * NV + tid] = a;
     }
 }
 
@@ -227,40 +287,54 @@ __global__ void __launch_bounds__(GN_NT)
     if (items1 > total) items1 = total;
     const size_t ibase = (size_t)img * HW;
     const size_t obase = (size_t)img * HWo;
-    for (int it = items0 + tid; it < items1; it += GN_NT) {
+    typedef typename GnVec<T>::Raw Raw;
+    auto one_item = [&](int it, const Raw& r0, const Raw& r1, const Raw& r2, const Raw& r3) {
+        float v0[V], v1[V], v2[V], v3[V];
+        GnVec<T>::expand(r0, v0);
+        if (POOL) { GnVec<T>::expand(r1, v1); GnVec<T>::expand(r2, v2); GnVec<T>::expand(r3, v3); }
         const int po = it / CQ;
-        const int qd = it - po * CQ;
-        const int c = qd * V;
+        const int c = (it - po * CQ) * V;
         float y[V];
-        if (POOL) {
-            const int oy = po / Wo, ox = po - oy * Wo;
-            const size_t pi = ibase + (size_t)(2 * oy) * W + 2 * ox;
 #pragma unroll
-            for (int e = 0; e < V; ++e) y[e] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v[V];
-                GnVec<T>::load(gn_ptr(s, pi + (k >> 1) * W + (k & 1), c), v);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float t = v[e] * cA[c + e] + cB[c + e];
-                    if (silu) t = fast_silu(t);
-                    y[e] += t;
-                }
+        for (int e = 0; e < V; ++e) {
+            const float a = cA[c + e], b = cB[c + e];
+            float t = v0[e] * a + b;
+            if (silu) t = fast_silu(t);
+            if (POOL) {
+                float t1 = v1[e] * a + b, t2 = v2[e] * a + b, t3 = v3[e] * a + b;
+                if (silu) { t1 = fast_silu(t1); t2 = fast_silu(t2); t3 = fast_silu(t3); }
+                t = (t + t1 + t2 + t3) * 0.25f;
             }
-#pragma unroll
-            for (int e = 0; e < V; ++e) y[e] *= 0.25f;
-        } else {
-            float v[V];
-            GnVec<T>::load(gn_ptr(s, ibase + po, c), v);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                float t = v[e] * cA[c + e] + cB[c + e];
-                if (silu) t = fast_silu(t);
-                y[e] = t;
-            }
+            y[e] = t;
         }
         GnVec<T>::store(out + (obase + po) * ldo + c, y);
+    };
+    auto src_of = [&](int it, int k) -> const T* {
+        const int po = it / CQ;
+        const int c = (it - po * CQ) * V;
+        if (POOL) {
+            const int oy = po / Wo, ox = po - oy * Wo;
+            return gn_ptr(s, ibase + (size_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1), c);
+        }
+        return gn_ptr(s, ibase + po, c);
+    };
+    constexpr int UA = POOL ? 1 : 4;              // items per trip (a pooled item already has 4 loads in flight)
+    int it = items0 + tid;
+    for (; it + (UA - 1) * GN_NT < items1; it += UA * GN_NT) {
+        Raw v[UA][POOL ? 4 : 1];
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+#pragma unroll
+            for (int k = 0; k < (POOL ? 4 : 1); ++k) v[u][k] = GnVec<T>::raw(src_of(it + u * GN_NT, k));
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+            one_item(it + u * GN_NT, v[u][0], v[u][POOL ? 1 : 0], v[u][POOL ? 2 : 0], v[u][POOL ? 3 : 0]);
+    }
+    for (; it < items1; it += GN_NT) {
+        Raw v[POOL ? 4 : 1];
+#pragma unroll
+        for (int k = 0; k < (POOL ? 4 : 1); ++k) v[k] = GnVec<T>::raw(src_of(it, k));
+        one_item(it, v[0], v[POOL ? 1 : 0], v[POOL ? 2 : 0], v[POOL ? 3 : 0]);
     }
 }
 
@@ -327,10 +401,31 @@ __global__ void __launch_bounds__(128)
 // pixel chunks per image of the statistics pass: enough blocks to fill the chip (~2048), at least 4 pixels per
 // pixel-row of threads
 static void stats_geometry(int NI, int HW, int CQ, int* QX, int* PY, int* ppb, int* chunks) {
-    *QX = CQ < GN_NT ? CQ : (CQ + GN_MAXQ - 1) / GN_MAXQ;
-    *PY = GN_NT / *QX;
-    if (*PY < 1) *PY = 1;
-    int ch = (2048 + NI - 1) / NI;
+    // threads = PY pixel rows x QX channel vectors, each thread owning up to GN_MAXQ vectors QX apart: of the splits that
+    // cover CQ, take the one that keeps the most threads busy (e.g. 96 vectors: 5 rows x 48 x 2 = 240 threads, not 2 x 96)
+    int best_q = 0, best_active = -1;
+    for (int j = 1; j <= GN_MAXQ; ++j) {
+        const int qx = (CQ + j - 1) / j;
+        if (qx > GN_NT) continue;
+        const int active = (GN_NT / qx) * qx;
+        if (active > best_active) { best_active = active; best_q = qx; }
+    }
+    *QX = best_q > 0 ? best_q : GN_NT + 1;       // > GN_NT: rejected by the caller
+    *PY = best_q > 0 ? GN_NT / best_q : 1;
+    // blocks per launch: a block's fixed tail (LDS fold, partial store, ticket) costs about as much as streaming 100 KB,
+    // so blocks get >= 128 KiB each, between one and four per CU (measured: 64x64x192 fp32 x 64 images 45 us with 2048
+    // blocks, 36 us with 1024; 16x16x576 20 us -> 15 us with 512).  ND_GN_BLOCKS overrides (tuning knob).
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("ND_GN_BLOCKS");
+        forced = e ? atoi(e) : 0;
+        if (forced < 0) forced = 0;
+    }
+    long target = (long)NI * HW * CQ * 16 / (128 << 10);
+    if (target < 256) target = 256;
+    if (target > 1024) target = 1024;
+    if (forced > 0) target = forced;
+    int ch = (int)((target + NI - 1) / NI);
     int pb = (HW + ch - 1) / ch;
     if (pb < 4 * *PY) pb = 4 * *PY;
     *ppb = pb;
