@@ -19,6 +19,10 @@
 //   D^T = W.X^T a lane ends up with ONE pixel and 4 consecutive output channels per register group: 8-byte bf16 stores.
 #include "nd_conv_common.h"
 
+#ifndef ND_BF16_SCHED
+#define ND_BF16_SCHED 1
+#endif
+
 namespace nd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -124,6 +128,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int c = ch * (64 * NSUB) + (hslot << 3);
+#if defined(ND_HABL_NOHALO)      // timing-only ablation: only chunk 0 is ever fetched
+        if (ch > 0) { asm volatile("" :: "v"(g)); return v; }
+#endif
         if (g >= 0 && c < Ctot) {
             const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
             v = *reinterpret_cast<const f32x4*>(src);
@@ -171,14 +178,16 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // register set -- the slot of tile mi for the NEXT k-step is re-read right behind the MFMAs that consumed it and has
     // the other TM-1 tiles' MFMAs (>= 190 cycles) to land; 128 accumulator + 16 + 24 operand registers leave room for
     // two waves per SIMD.
-    constexpr int RING = (TAPS == 9) ? 3 : 4;
+    constexpr int RING = (TAPS == 9) ? 3 : 4;      // measured: deeper rings (6 / 8 on the small register tiles) are slower
     constexpr int BDIST = RING - 1;
     f32x4 a_fr[TM], b_fr[RING][TN];
     // the packed buffer carries a whole zero chunk at the end, so the stream may always run ahead
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
+#if !defined(ND_HABL_NOB)        // timing-only ablation: weight fragments stay whatever the registers hold
             dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+#endif
             bp[ni] += 512;
         }
         if (++ld_in_c64 == STEPS) {
@@ -196,8 +205,21 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bw[ni]), as_bf16x8(a_fr[mi]), acc[mi][ni], 0, 0, 0);
+#if !defined(ND_HABL_NOA)        // timing-only ablation: no LDS fragment reads
             a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + noff[mi]);
+#else
+            asm volatile("" :: "v"(noff[mi]));
+#endif
         }
+#if ND_BF16_SCHED && !defined(ND_HABL_NOA)
+        // pin the interleave: TN MFMAs, then the one LDS read that refills the fragment they consumed (left alone the
+        // scheduler sinks all TM reads behind the last MFMA, so the next step opens waiting for LDS)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
         ND_PRIO(0);
     };
 
@@ -270,8 +292,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             }
         } else {
             // 1x1: KSTEPS k-steps per chunk; the next chunk's rows are fetched one group of NBI per step and parked two
-            // steps later (the last two groups behind the loop)
+            // steps later (the last groups behind the loop)
             f32x4 ph[KSTEPS][NBI];
+            constexpr int SD = 2;      // k-steps between a group's fetch and its LDS store
             const bool second = (ch * NSUB + 1) < p.NC64;          // the chunk's second 64-channel half holds real channels
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -292,22 +315,27 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
                     for (int i = 0; i < NBI; ++i) ph[ks][i] = load_halo_pixel(halo_next ? gpix[ks * NBI + i] : -1, ch + 1);
                 }
-                if (ks >= 2 && halo_next) {
+                if (ks >= SD && halo_next) {
 #pragma unroll
-                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - 2) * NBI + i, (ch + 1) & 1, ph[ks - 2][i]);
+                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - SD) * NBI + i, (ch + 1) & 1, ph[ks - SD][i]);
                 }
             }
             if (halo_next) {
 #pragma unroll
-                for (int ks = KSTEPS - 2; ks < KSTEPS; ++ks)
+                for (int ks = KSTEPS - SD; ks < KSTEPS; ++ks)
 #pragma unroll
                     for (int i = 0; i < NBI; ++i) store_halo_item(ks * NBI + i, (ch + 1) & 1, ph[ks][i]);
             }
         }
         // halo hand-over: only LDS traffic has to be complete; the weight prefetch stays in flight across the barrier
+#if !defined(ND_HABL_NOBAR)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
     }
+#if defined(ND_HABL_NOEPI)
+    if (p.N > 0) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.out)[0] = acc[0][0][1]; return; }
+#endif
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);

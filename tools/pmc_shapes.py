@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Per-shape HBM traffic (and matrix-pipe occupancy) of every convolution launch of a forward, IN the forward:
+
+    python tools/pmc_shapes.py <workload> <fetch_dir> <write_dir> [<sq_dir>]  ->  profiles/r02_pmc_shapes.json (merged)
+
+Inputs are the rocprofv3 output directories of separate --pmc passes over tools/pmc_forward.py (tools/pmc_shapes.sh runs
+them): FETCH_SIZE, WRITE_SIZE and optionally GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES.  The
+conv dispatches of the last `reps` forwards are matched, in order, with the plan's launch list, and averaged per key
+    kind:variant:NI:H:W:Cin:N
+HBM bytes per launch = FETCH_SIZE [KiB] x 1024 x 2 (gfx950 counts 128-byte read requests as 64 bytes:
+MI355X_MICROARCH.md, HBM section) + WRITE_SIZE [KiB] x 1024.  bench.py looks its dominant kernel's shapes up here."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc')
+CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino_kernel', 'conv_mfma_kernel', 'gemm_stream_kernel',
+                'conv_bf16_kernel')
+
+
+def dispatches(d):
+    """[(dispatch id, kernel name, {counter: value}, duration_us)] of the conv kernels, in dispatch order."""
+    cc = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(cc)):
+        if not any(k in r['Kernel_Name'] for k in CONV_KERNELS) or 'pack_' in r['Kernel_Name']:
+            continue
+        e = acc.setdefault(int(r['Dispatch_Id']), [r['Kernel_Name'], collections.defaultdict(float), None])
+        e[1][r['Counter_Name']] += float(r['Counter_Value'])
+    kt = glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv')
+    if kt:
+        for r in csv.DictReader(open(kt[0])):
+            i = int(r['Dispatch_Id'])
+            if i in acc:
+                acc[i][2] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    return [(i,) + tuple(v) for i, v in sorted(acc.items())]
+
+
+def main():
+    wl, dirs = sys.argv[1], sys.argv[2:]
+    ops = json.load(open(os.path.join(ROOT, 'gpurun_out', 'pmc_ops_{}.json'.format(wl))))
+    convs = [m for m in ops['ops'] if m['fn'] in CONV_FNS]
+    reps = ops['reps']
+    per_key = collections.OrderedDict()
+    for d in dirs:
+        disp = dispatches(d)
+        need = reps * len(convs)
+        assert len(disp) >= need, '{}: {} conv dispatches < {} forwards x {} convs'.format(d, len(disp), reps, len(convs))
+        disp = disp[-need:]
+        for j, (_, kname, ctr, us) in enumerate(disp):
+            m = convs[j % len(convs)]
+            kind, var = m['variant'] if m.get('variant') else ('direct', -1)
+            shape = m.get('shape') or [0, 0, 0, 0, 0]
+            key = '{}:{}:{}'.format(kind, var, ':'.join(str(v) for v in shape))
+            e = per_key.setdefault(key, dict(kernel=kname.split('(')[0], label=m['label'], ksize=m.get('ksize'), flops=m['flops'],
+                                             n=collections.defaultdict(int), sums=collections.defaultdict(float)))
+            assert e['kernel'] == kname.split('(')[0], 'dispatch order does not match the plan at {}: {} vs {}'.format(
+                key, e['kernel'], kname)
+            for c, v in ctr.items():
+                e['sums'][c] += v
+                e['n'][c] += 1
+            if us is not None:
+                e['sums']['_us'] += us
+                e['n']['_us'] += 1
+    esize = 2 if ops['dtype'] == 'bf16' else 4
+
+    def key_of(m):
+        kind, var = m['variant'] if m.get('variant') else ('direct', -1)
+        return '{}:{}:{}'.format(kind, var, ':'.join(str(v) for v in (m.get('shape') or [0, 0, 0, 0, 0])))
+    counts = collections.Counter(key_of(m) for m in convs)
+    out = {}
+    tot_h = tot_a = 0.0
+    for key, e in per_key.items():
+        avg = {c: e['sums'][c] / e['n'][c] for c in e['sums']}
+        rec = dict(kernel=e['kernel'], label=e['label'], launches_per_forward=counts[key],
+                   duration_us=round(avg.get('_us', 0.0), 1), flops=e['flops'])
+        NI, H, W, Cin, N = [int(v) for v in key.split(':')[2:]]
+        k = e['ksize'] or 1
+        rec['algorithmic_bytes'] = esize * (NI * H * W * (Cin + N) + k * k * Cin * N)
+        if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg and rec['algorithmic_bytes'] > 0:
+            rec['fetch_kib_raw'] = round(avg['FETCH_SIZE'], 1)
+            rec['write_kib'] = round(avg['WRITE_SIZE'], 1)
+            rec['hbm_bytes'] = int(avg['FETCH_SIZE'] * 1024 * 2 + avg['WRITE_SIZE'] * 1024)
+            rec['traffic_ratio'] = round(rec['hbm_bytes'] / rec['algorithmic_bytes'], 3)
+        if 'GRBM_GUI_ACTIVE' in avg and avg['GRBM_GUI_ACTIVE'] > 0:
+            cyc = avg['GRBM_GUI_ACTIVE'] / 8
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in avg:
+                rec['mfma_busy'] = round(avg['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc, 4)      # 256 CUs x 4 SIMDs
+            if avg.get('_us'):
+                rec['clock_ghz'] = round(cyc / avg['_us'] / 1e3, 3)
+        if avg.get('SQ_WAVE_CYCLES'):
+            rec['wait_any'] = round(avg.get('SQ_WAIT_ANY', 0.0) / avg['SQ_WAVE_CYCLES'], 4)
+        out[key] = rec
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_shapes.json')
+    merged = {}
+    if os.path.exists(path):
+        merged = json.load(open(path))
+    merged.update(out)
+    # per-kernel totals over one forward of this workload
+    by_kernel = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for key, rec in out.items():
+        if 'hbm_bytes' in rec:
+            n = counts[key]
+            by_kernel[rec['kernel']][0] += rec['hbm_bytes'] * n
+            by_kernel[rec['kernel']][1] += rec['algorithmic_bytes'] * n
+            by_kernel[rec['kernel']][2] += n
+    merged['_totals_' + wl] = {k: dict(hbm_bytes_per_forward=int(v[0]), algorithmic_bytes_per_forward=int(v[1]),
+                                       ratio=round(v[0] / v[1], 3), launches=v[2]) for k, v in by_kernel.items()}
+    merged['_comment'] = ('Generated by tools/pmc_shapes.sh (rocprofv3 --pmc passes over tools/pmc_forward.py, separate passes for '
+                          'FETCH_SIZE / WRITE_SIZE / SQ counters) and tools/pmc_shapes.py; key = kind:variant:NI:H:W:Cin:N of a '
+                          'conv launch IN the forward; hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x '
+                          '1024 per launch; algorithmic_bytes = esize x (input + output elements + weights).')
+    json.dump(merged, open(path, 'w'), indent=1, sort_keys=True)
+    for k, v in merged['_totals_' + wl].items():
+        print(k, v)
+
+
+if __name__ == '__main__':
+    main()
