@@ -399,6 +399,267 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 form with BOTH operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write).
+// Ablations of the kernel above put the weight-fragment stream (global -> VGPR per wave, two waves fetching every
+// fragment, in-order vmcnt coupling it to the halo fetches) at 1.4x of the run time.  Here a block's weight fragments
+// cross L2 -> CU once: per tap the 8 waves DMA the tap's 4 k-steps x BN/32 fragments (32 KiB for BN = 256) into one of
+// two LDS stages while the previous stage is consumed; the next chunk's halo goes the same way, one 1 KiB piece per wave
+// and tap, with the XOR swizzle applied to the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  One
+// "vmcnt(0) + barrier" per tap publishes everything issued during the tap; nothing is counted by hand.
+#define ND_GLDS16H(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(WM* WN * 64, 2)
+    conv_bf16w_kernel(const ConvArgsH p, const __bf16* zero16) {
+    constexpr int NW = WM * WN;
+    constexpr int BN = WN * TN * 32;
+    constexpr int NTB = BN / 32;                       // n tiles per block
+    constexpr int STAGE_W = 4 * NTB * 256;             // 4-byte words per weight stage (one tap: 4 k-steps x NTB fragments)
+    constexpr int NFW = 4 * NTB / NW;                  // weight DMAs per wave and tap
+    static_assert(4 * NTB % NW == 0, "");
+    constexpr int ROWF = 32;                           // words per halo pixel row (64 bf16 channels)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 halo buffers][2 weight stages]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+    const int NPIECE = (HP * 8 + 63) >> 6;             // 1 KiB pieces per halo buffer
+    const int HBUF_W = NPIECE * 256;                   // words per halo buffer
+    float* wring = smem + 2 * HBUF_W;
+
+    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
+
+    // ---- halo DMA descriptors: piece u = k * NW + wave (k = tap that issues it); lane -> 16-byte unit U = u*64 + lane =
+    //      physical slot U & 7 of halo pixel U >> 3, which holds logical channel slot (U & 7) ^ swz(pixel)
+    const int Ctot = p.C0 + p.C1;
+    int gpx[9];
+    int hsl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int U = (k * NW + wave) * 64 + lane;
+        const int hp = U >> 3;
+        int g = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpx[k] = g;
+        hsl[k] = ((U & 7) ^ swz(hp)) << 3;
+    }
+    auto issue_halo = [&](int k, int ch, int buf) {     // wave-uniform guard: pieces past the buffer are not issued
+        const int u = k * NW + wave;
+        if (u < NPIECE) {
+            const int c = ch * 64 + hsl[k];
+            const int g = gpx[k];
+            const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
+                                           : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
+            src = (g >= 0 && c < Ctot) ? src : zero16;
+            ND_GLDS16H(src, smem + buf * HBUF_W + u * 256);
+        }
+    };
+
+    // ---- weight DMAs: fragment f = j * NW + wave of a tap stage = (k-step f / NTB, n tile f % NTB)
+    const __bf16* wsrc[NFW];
+    int wdst[NFW];
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+        const int f = j * NW + wave;
+        const int ks = f / NTB, nl = f - ks * NTB;
+        int ntile = nblk * NTB + nl;
+        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
+        wsrc[j] = p.w + ((size_t)ntile * 36 + ks) * 512 + lane * 8;
+        wdst[j] = (ks * NTB + nl) * 256;
+    }
+    const size_t c64_stride = (size_t)p.NT32 * 36 * 512;
+    auto issue_w = [&](int ch, int tap, int stage) {
+#pragma unroll
+        for (int j = 0; j < NFW; ++j)
+            ND_GLDS16H(wsrc[j] + (size_t)ch * c64_stride + tap * (4 * 512), wring + stage * STAGE_W + wdst[j]);
+    };
+
+    int a_hp[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 32 + l31;
+        const int li = m >> (p.thl + p.twl);
+        const int py = (m >> p.twl) & (TH - 1);
+        const int px = m & (TW - 1);
+        a_hp[mi] = li * HPI + py * HW + px;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    const int nchunks = p.NC64;
+    // ---- prologue: chunk 0 halo (all pieces), tap 0 weights
+#pragma unroll
+    for (int k = 0; k < 9; ++k) issue_halo(k, 0, 0);
+    issue_w(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int gt = 0;                                         // global tap counter: weight stage = gt & 1
+    f32x4 a_fr[TM], b_fr[2][TN];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * HBUF_W;
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx, ++gt) {
+                const int tap = dy * 3 + dx;
+                const float* wst = wring + (gt & 1) * STAGE_W + ((wn * TN) * 64 + lane) * 4;
+                // fill the other stage with the next tap (past the last chunk: the packed tensor's zero chunk) and send
+                // this tap's piece of the next chunk's halo on its way
+                {
+                    const int ntap = (tap == 8) ? 0 : tap + 1;
+                    issue_w(ch + (tap == 8 ? 1 : 0), ntap, (gt + 1) & 1);
+                    if (ch + 1 < nchunks) issue_halo(tap, ch + 1, (ch + 1) & 1);
+                }
+                const int tapoff = dy * HW + dx;
+                // this tap's first fragments
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) b_fr[0][ni] = *reinterpret_cast<const f32x4*>(wst + ni * 256);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int hp = a_hp[mi] + tapoff;
+                    a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
+                }
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int cur = kc & 1, nxt = cur ^ 1;
+                    if (kc < 3) {
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            b_fr[nxt][ni] = *reinterpret_cast<const f32x4*>(wst + ((kc + 1) * NTB + ni) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ND_PRIO(1);
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b_fr[cur][ni]), as_bf16x8(a_fr[mi]),
+                                                                                  acc[mi][ni], 0, 0, 0);
+                        if (kc < 3) {
+                            const int hp = a_hp[mi] + tapoff;
+                            const int nslot = ((kc + 1) << 1) | lh;
+                            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
+                        }
+                    }
+                    if (kc < 3) {
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    ND_PRIO(0);
+                }
+                // publish: every DMA this wave issued during the tap has landed, every LDS read of the tap is done
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // ---- epilogue (as conv_bf16_kernel): lane = one pixel, register group g4 = 4 consecutive output channels
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 32 + l31;
+        const int li = m >> (p.thl + p.twl);
+        const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+        const int ox = ox0 + (m & (TW - 1));
+        const int img = img0 + li;
+        if (img < p.NI && oy < p.H && ox < p.W) {
+            const size_t opix = (size_t)(img * p.H + oy) * p.W + ox;
+            const float* rb = p.rowbias ? p.rowbias + (size_t)img * p.ld_rowbias : nullptr;
+            const __bf16* rr = nullptr;
+            if (p.res) {
+                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
+                rr = p.res + rp * p.ldr;
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                    if (n + 3 < p.N && vec_ok) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+                        if (rr) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        if (p.out_f32) {
+                            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + opix * p.ldo + n) = v;
+                        } else {
+                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = acc[mi][ni][4 * g4 + e];
+                                if (p.bias) v += p.bias[n + e];
+                                if (rb) v += rb[n + e];
+                                if (rr) v += (float)rr[n + e];
+                                if (p.silu_out) v = fast_silu(v);
+                                if (p.out_f32) static_cast<float*>(p.out)[opix * p.ldo + n + e] = v;
+                                else static_cast<__bf16*>(p.out)[opix * p.ldo + n + e] = (__bf16)v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 OIHW [N][C][k][k] (also Conv1d [N][C][1], Linear [N][C]) -> bf16 fragment order
 //   out[((((c64*NT32 + ntile)*taps + tap)*4 + ks)*64 + lane)*8 + j] = bf16(w[n = ntile*32 + (lane&31)][c = c64*64 + ks*16 + (lane>>5)*8 + j][tap])
 // zero for n >= N, c >= C and for the padding chunks.
@@ -432,24 +693,36 @@ __global__ void f32_to_bf16_rows_kernel(const float* x, int ldx, __bf16* out, in
 // ------------------------------------------------------------------------------------------------------------
 struct VariantH {
     int wm, wn, tm, tn;
+    int ldsw;       // 1: conv_bf16w_kernel (3x3 only; weights and halo through LDS by LDS-DMA)
     int bm() const { return wm * tm * 32; }
     int bn() const { return wn * tn * 32; }
     int nt() const { return wm * wn * 64; }
 };
 
 static const VariantH kVariantsH[] = {
-    {2, 4, 4, 2},   // 0: 256 x 256, 8 waves
-    {2, 2, 4, 2},   // 1: 256 x 128, 4 waves
-    {2, 4, 4, 1},   // 2: 256 x 128, 8 waves
-    {2, 4, 2, 2},   // 3: 128 x 256, 8 waves
-    {2, 2, 2, 2},   // 4: 128 x 128, 4 waves
-    {2, 4, 2, 1},   // 5: 128 x 128, 8 waves
-    {2, 2, 2, 1},   // 6: 128 x  64, 4 waves
-    {2, 2, 1, 1},   // 7:  64 x  64, 4 waves
+    {2, 4, 4, 2, 0},   // 0: 256 x 256, 8 waves
+    {2, 2, 4, 2, 0},   // 1: 256 x 128, 4 waves
+    {2, 4, 4, 1, 0},   // 2: 256 x 128, 8 waves
+    {2, 4, 2, 2, 0},   // 3: 128 x 256, 8 waves
+    {2, 2, 2, 2, 0},   // 4: 128 x 128, 4 waves
+    {2, 4, 2, 1, 0},   // 5: 128 x 128, 8 waves
+    {2, 2, 2, 1, 0},   // 6: 128 x  64, 4 waves
+    {2, 2, 1, 1, 0},   // 7:  64 x  64, 4 waves
+    // one pixel row of waves: every wave owns its own n tile(s), so no weight fragment is fetched twice by a block
+    {1, 8, 8, 1, 0},   // 8: 256 x 256, 8 waves, wave tile 256 px x 32 ch
+    {1, 4, 8, 1, 0},   // 9: 256 x 128, 4 waves
+    {1, 8, 4, 1, 0},   // 10: 128 x 256, 8 waves
+    {1, 4, 4, 2, 0},   // 11: 128 x 256, 4 waves, wave tile 128 px x 64 ch
+    // both operands through LDS (LDS-DMA), 3x3 only
+    {2, 4, 4, 2, 1},   // 12: 256 x 256, 8 waves
+    {2, 4, 2, 2, 1},   // 13: 128 x 256, 8 waves
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
 static size_t lds_bytes_h(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 128 : 256); }
+static size_t lds_bytes_w(const VariantH& V, int hp) {
+    return (size_t)2 * ((hp * 8 + 63) / 64) * 1024 + (size_t)2 * 4 * (V.bn() / 32) * 1024;
+}
 
 static int nbi_of(const VariantH& V, int taps) {
     return taps == 9 ? (((V.bm() * 25 + 2 * V.nt() - 1) / (2 * V.nt()) + 2) / 3) : ((V.bm() * 16 / V.nt() + 7) / 8);
@@ -467,8 +740,13 @@ static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, Tile
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2 * pad) * (TW + 2 * pad);
-            if ((long)hp * spr > (long)maxhi * nt) continue;
-            if (lds_bytes_h(taps, hp) > 160 * 1024) continue;
+            if (V.ldsw) {
+                if ((hp * 8 + 63) / 64 > 9 * (nt / 64)) continue;        // one 1 KiB halo piece per wave and tap
+                if (lds_bytes_w(V, hp) > 160 * 1024) continue;
+            } else {
+                if ((long)hp * spr > (long)maxhi * nt) continue;
+                if (lds_bytes_h(taps, hp) > 160 * 1024) continue;
+            }
             TilePlan t;
             t.thl = thl; t.twl = twl; t.nibl = nibl;
             t.tiles_x = (W + TW - 1) / TW;
@@ -494,11 +772,12 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
     for (int v = 0; v < kNumVariantsH; ++v) {
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
+        if (V.ldsw && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
         TilePlan tp;
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
         const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = lds_bytes_h(taps, tp.hp);
+        const size_t lds = V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp);
         int per_cu = (int)(160 * 1024 / lds);
         const int by_waves = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;      // two waves per SIMD
         if (per_cu > by_waves) per_cu = by_waves;
@@ -525,6 +804,15 @@ static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     return check_launch("nd_conv_bf16_nhwc");
 }
 
+template <int WM, int WN, int TM, int TN>
+static int launch_w(const ConvArgsH& a, const __bf16* zero16, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_bf16w_kernel<WM, WN, TM, TN>;
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a, zero16);
+    return check_launch("nd_conv_bf16_nhwc");
+}
+
 template <int TAPS>
 static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     switch (v) {
@@ -536,6 +824,10 @@ static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream
         case 5: return launch_h<2, 4, 2, 1, TAPS>(a, grid, lds, s);
         case 6: return launch_h<2, 2, 2, 1, TAPS>(a, grid, lds, s);
         case 7: return launch_h<2, 2, 1, 1, TAPS>(a, grid, lds, s);
+        case 8: return launch_h<1, 8, 8, 1, TAPS>(a, grid, lds, s);
+        case 9: return launch_h<1, 4, 8, 1, TAPS>(a, grid, lds, s);
+        case 10: return launch_h<1, 8, 4, 1, TAPS>(a, grid, lds, s);
+        case 11: return launch_h<1, 4, 4, 2, TAPS>(a, grid, lds, s);
     }
     set_error("nd_conv_bf16_nhwc: bad variant %d", v);
     return ND_E_ARG;
@@ -646,7 +938,17 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
     const int grid = a.mt * a.nt;
-    const size_t lds = lds_bytes_h(taps, tp.hp);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (V.ldsw) {
+        // 16 bytes of zeros for padded halo units: the tail of the packed weights' trailing zero chunk
+        const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;
+        const size_t ldsw = lds_bytes_w(V, tp.hp);
+        switch (v) {
+            case 12: return launch_w<2, 4, 4, 2>(a, zero16, grid, ldsw, s);
+            case 13: return launch_w<2, 4, 2, 2>(a, zero16, grid, ldsw, s);
+        }
+        return fail_arg(fn, "bad variant");
+    }
+    const size_t lds = lds_bytes_h(taps, tp.hp);
     return (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
 }
