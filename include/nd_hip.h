@@ -161,32 +161,31 @@ int64_t nd_conv_weight_floats(int N, int C, int ksize);
 int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, nd_stream_t stream);
 
 /* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1); activations fp32 or bf16 (`dtype`) ---------
- * stats: per (img, group) sum and sum of squares of (x + addvec[img,c]) in float64 -> stats[NI][G][2], WRITTEN (not
- *   accumulated) and bitwise reproducible: fixed-order tree inside a block, per-block partials in `workspace`, the
- *   last block of an image (ticket) adds them in block order -- no floating-point atomics.  `workspace` holds
- *   nd_groupnorm_stats_workspace_bytes(...) bytes, 256-byte aligned, its first NI int32 (the tickets) ZERO on entry
- *   (they are left zero), and may be shared by launches that are stream-ordered.  addvec [NI][ld_add] | NULL is the
- *   non-adaptive timestep-embedding add that precedes out_norm (model.py:205).
+ * stats: per (img, block, group) sum and sum of squares of (x + addvec[img,c]) in float64 ->
+ *   partials[NI][nblocks][G][2], nblocks = nd_groupnorm_stats_blocks(NI, HW, C, dtype); every entry is WRITTEN (nothing
+ *   to zero) and bitwise reproducible: fixed-order folds inside a block, and the consumers below add the blocks'
+ *   partials in block order -- no atomics at all.  addvec [NI][ld_add] | NULL is the non-adaptive
+ *   timestep-embedding add that precedes out_norm (model.py:205).
  * apply: y = ((x+addvec) - mean) * rstd * gamma + beta;  if scale: y = y*(1+scale[img,c]) + shift[img,c]
  *   (model.py:201-203); optional SiLU (model.py:190,207,447); optional 2x2 average pool of the result
  *   (model.py:111 applied to h, :192).  eps as nn.GroupNorm (1e-5).  out has the input's element type.
  */
-int64_t nd_groupnorm_stats_workspace_bytes(int NI, int HW, int C, int G, int dtype);
+int nd_groupnorm_stats_blocks(int NI, int HW, int C, int dtype);
 int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                            const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW, int G,
+                            const float* addvec, int ld_add, double* partials, int NI, int HW, int G,
                             int dtype, nd_stream_t stream);
 /* Partial output statistics written by nd_conv3x3_winograd_stats_nhwc (p0: rows0 = mbi*4 partial rows per image over C0
- * channels; optionally concatenated with p1 over C1 channels) -> WRITES the per-group sums to stats [NI][G][2] (the
- * array nd_groupnorm_stats_nhwc fills), summed in a fixed order. */
+ * channels; optionally concatenated with p1 over C1 channels) -> WRITES the per-group sums to stats [NI][1][G][2] (the
+ * nblocks = 1 form of what nd_groupnorm_stats_nhwc fills), summed in a fixed order. */
 int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
                                      double* stats, int NI, int G, nd_stream_t stream);
 /* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions
  * that apply it while loading their input (gnA/gnB of nd_conv_nhwc / nd_conv3x3_winograd_nhwc). */
-int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
+int nd_groupnorm_coeffs(const double* partials, int nblocks, const float* gamma, const float* beta, const float* scale,
                         const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
                         int NI, int C, int HW, int G, float eps, nd_stream_t stream);
 int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                            const float* addvec, int ld_add, const double* stats,
+                            const float* addvec, int ld_add, const double* partials, int nblocks,
                             const float* gamma, const float* beta,
                             const float* scale, const float* shift, int ld_ss,
                             void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,

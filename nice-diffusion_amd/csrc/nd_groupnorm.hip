@@ -12,9 +12,10 @@
 // rate is far above what the stream needs, and E[x^2]-E[x]^2 in float64 has no cancellation problem for fp32 data).
 // Everything after the per-thread sums runs in a FIXED order, so the statistics are bitwise reproducible from run
 // to run: the pixel rows of a block are folded through LDS in row order, the channels of a group in channel order,
-// each block stores its per-(image, group) partial (agent-scope stores), and the block that draws the last ticket of its
-// image (one relaxed integer atomic) adds the partials in block order and writes the statistics.  No floating-point
-// atomics anywhere.  Pass 2 (apply) folds mean/rstd/gamma/beta and the AdaGN scale/shift into one FMA
+// each block stores its per-(image, group) partial [img][block][G][2] with plain stores and is done; the CONSUMER kernel
+// (apply / coefficients, a later launch on the same stream) adds the blocks' partials in block order in its prologue.
+// No atomics, no tickets, no fences anywhere (a first version with a last-block ticket paid a per-block tail that cost
+// more than the stream itself on 8x8 .. 32x32 maps).  Pass 2 (apply) folds mean/rstd/gamma/beta and the AdaGN scale/shift into one FMA
 // per element (coefficients staged in LDS per block), applies SiLU and optionally the 2x2 average pool, and writes
 // 16 bytes per lane.
 #include "nd_common.h"
@@ -72,10 +73,10 @@ __device__ __forceinline__ const T* gn_ptr(const GnSrc<T>& s, size_t pix, int c)
 }
 
 // grid: (pixel chunks, NI).  Threads are laid out as PY pixel rows x QX channel vectors.
-// ws: tickets int32 [NI] (zero on entry, left zero) followed (256-byte offset) by partials double [NI][chunks][G][2].
+// partials: double [NI][gridDim.x][G][2], every entry written.
 template <typename T>
 __global__ void __launch_bounds__(GN_NT)
-    gn_stats_kernel(GnSrc<T> s, const float* addvec, int ld_add, double* stats, int* tickets, double* partials, int HW,
+    gn_stats_kernel(GnSrc<T> s, const float* addvec, int ld_add, double* partials, int HW,
                     int G, int QX, int PY, int pix_per_block) {
     constexpr int V = GnVec<T>::N;
     extern __shared__ __attribute__((aligned(16))) double sh[];   // [PY][C][2], reused for [C][2] and the group sums
@@ -184,71 +185,37 @@ __global__ void __launch_bounds__(GN_NT)
             a += sh[c * 2];
             b += sh[c * 2 + 1];
         }
-        if (nchunks == 1) {                                               // single block per image: final already
-            double* dst = stats + ((size_t)img * G + tid) * 2;
-            dst[0] = a;
-            dst[1] = b;
-        } else {
-            // hand-off to the last block of the image: agent-scope (sc1, write-through) stores and loads of the partials
-            // themselves, so that no release / acquire fence -- an L2 write-back and invalidate per block, with the
-            // producing convolution's output still dirty in L2 -- is needed around the ticket
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(partials) +
-                                      (((size_t)img * nchunks + blockIdx.x) * G + tid) * 2;
-            __hip_atomic_store(dst, __double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, __double_as_longlong(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        double* dst = partials + (((size_t)img * nchunks + blockIdx.x) * G + tid) * 2;
+        dst[0] = a;
+        dst[1] = b;
     }
-    if (nchunks == 1) return;
-    // every partial of this block is out (vmcnt drained, then the barrier) before thread 0 draws the ticket; the block
-    // that draws the last ticket of its image adds the partials in block order
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(sh);
-    if (tid == 0) {
-        const int t = __hip_atomic_fetch_add(&tickets[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == nchunks - 1) ? 1 : 0;
-        if (last) __hip_atomic_store(&tickets[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-    // value v = tid % (2G) (sum | sum of squares of a group), lane kq = tid / (2G) of KQ takes the blocks k = kq, kq + KQ, ...
-    // in order with 8 loads in flight; the KQ partial sums are then added in lane order: a fixed order all the way
-    const int NV = 2 * G;
-    const int KQ = GN_NT / NV;                    // >= 2 (G <= 128 is checked on the host; G = 32 gives 4)
-    const int vi = tid % NV, kq = tid / NV;
+}
+
+// sum of the per-block partials of (image, group g): element s (0 = sum, 1 = sum of squares), in block order.
+// Called by the first 2G threads of a consumer block; the result goes to LDS.
+__device__ __forceinline__ double gn_fold_partials(const double* partials, int img, int nchunks, int G, int idx) {
+    const double* src = partials + (size_t)img * nchunks * G * 2 + idx;
     double acc = 0.0;
-    if (kq < KQ) {
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(partials) + (size_t)img * nchunks * NV + vi;
-        for (int k0 = kq; k0 < nchunks; k0 += 8 * KQ) {
-            unsigned long long r[8];
+    int k = 0;
+    for (; k + 8 <= nchunks; k += 8) {
+        double r[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * KQ;
-                r[u] = (k < nchunks) ? __hip_atomic_load(src + (size_t)k * NV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            }
+        for (int u = 0; u < 8; ++u) r[u] = src[(size_t)(k + u) * G * 2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += __longlong_as_double(r[u]);       // 0ull is +0.0
-        }
+        for (int u = 0; u < 8; ++u) acc += r[u];
     }
-    __syncthreads();                              // everyone has read the flag word before sh is reused
-    if (kq < KQ) sh[kq * NV + vi] = acc;
-    __syncthreads();
-    if (tid < NV) {
-        double a = sh[tid];
-        for (int j = 1; j < KQ; ++j) a += sh[j * NV + tid];
-        stats[(size_t)img * NV + tid] = a;
-    }
+    for (; k < nchunks; ++k) acc += src[(size_t)k * G * 2];
+    return acc;
 }
 
 // grid: (pixel chunks, NI); LDS: coefficient pairs A[c], B[c] so that y = x*A + B
 template <typename T, bool POOL>
 __global__ void __launch_bounds__(GN_NT)
-    gn_apply_kernel(GnSrc<T> s, const float* addvec, int ld_add, const double* stats, const float* gamma,
+    gn_apply_kernel(GnSrc<T> s, const float* addvec, int ld_add, const double* partials, int nchunks, const float* gamma,
                     const float* beta, const float* scale, const float* shift, int ld_ss, T* out, int ldo,
                     int H, int W, int G, float eps, int silu, int pix_per_block) {
     constexpr int V = GnVec<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float shf[];   // A[C] | B[C]
+    extern __shared__ __attribute__((aligned(16))) float shf[];   // A[C] | B[C] | group sums double [G][2]
     const int C = s.C0 + s.C1;
     const int CQ = C / V;
     const int img = blockIdx.y;
@@ -258,10 +225,13 @@ __global__ void __launch_bounds__(GN_NT)
     const double inv_n = 1.0 / ((double)cpg * (double)HW);
     float* cA = shf;
     float* cB = shf + C;
+    double* gs = reinterpret_cast<double*>(shf + 2 * C);        // C is a multiple of 4: 8-byte aligned
+    for (int i = tid; i < 2 * G; i += GN_NT) gs[i] = gn_fold_partials(partials, img, nchunks, G, i);
+    __syncthreads();
     for (int c = tid; c < C; c += GN_NT) {
         const int g = c / cpg;
-        const double su = stats[((size_t)img * G + g) * 2 + 0];
-        const double sq = stats[((size_t)img * G + g) * 2 + 1];
+        const double su = gs[g * 2 + 0];
+        const double sq = gs[g * 2 + 1];
         const double mean = su * inv_n;
         double var = sq * inv_n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -339,17 +309,20 @@ __global__ void __launch_bounds__(GN_NT)
 }
 
 // coefficients of the fused form: y = x * A[img][c] + B[img][c]  (consumed by the conv loaders)
-__global__ void gn_coeffs_kernel(const double* stats, const float* gamma, const float* beta, const float* scale,
-                                 const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef, int C, int HW,
-                                 int G, float eps) {
+__global__ void __launch_bounds__(256)
+    gn_coeffs_kernel(const double* partials, int nchunks, const float* gamma, const float* beta, const float* scale,
+                     const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef, int C, int HW, int G, float eps) {
+    __shared__ double gs[256];                        // [G][2], G <= 128
     const int img = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) gs[i] = gn_fold_partials(partials, img, nchunks, G, i);
+    __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int cpg = C / G;
     const int g = c / cpg;
     const double inv_n = 1.0 / ((double)cpg * (double)HW);
-    const double mean = stats[((size_t)img * G + g) * 2 + 0] * inv_n;
-    double var = stats[((size_t)img * G + g) * 2 + 1] * inv_n - mean * mean;
+    const double mean = gs[g * 2 + 0] * inv_n;
+    double var = gs[g * 2 + 1] * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     double a = rstd * (double)gamma[c];
@@ -434,28 +407,24 @@ static void stats_geometry(int NI, int HW, int CQ, int* QX, int* PY, int* ppb, i
 
 template <typename T>
 static int launch_stats(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                        const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW, int G,
-                        hipStream_t st) {
+                        const float* addvec, int ld_add, double* partials, int NI, int HW, int G, hipStream_t st) {
     constexpr int V = GnVec<T>::N;
     const int C = C0 + C1, CQ = C / V;
     int QX, PY, ppb, chunks;
     stats_geometry(NI, HW, CQ, &QX, &PY, &ppb, &chunks);
     ND_REQUIRE(QX <= GN_NT, fn, "too many channels");
-    ND_REQUIRE(chunks == 1 || workspace != nullptr, fn, "workspace needed (nd_groupnorm_stats_workspace_bytes)");
     GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
-    int* tickets = static_cast<int*>(workspace);
-    double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + (((size_t)NI * 4 + 255) & ~(size_t)255));
     const size_t lds = (size_t)PY * C * 2 * sizeof(double);
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats, tickets,
-                       partials, HW, G, QX, PY, ppb);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, partials, HW, G, QX,
+                       PY, ppb);
     return check_launch(fn);
 }
 
 template <typename T>
 static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                        const float* addvec, int ld_add, const double* stats, const float* gamma, const float* beta,
-                        const float* scale, const float* shift, int ld_ss, void* out, int ldo, int NI, int H, int W,
-                        int G, float eps, int flags, hipStream_t st) {
+                        const float* addvec, int ld_add, const double* stats, int nchunks, const float* gamma,
+                        const float* beta, const float* scale, const float* shift, int ld_ss, void* out, int ldo, int NI,
+                        int H, int W, int G, float eps, int flags, hipStream_t st) {
     constexpr int V = GnVec<T>::N;
     const int C = C0 + C1, CQ = C / V;
     ND_REQUIRE((ldo & (V - 1)) == 0 && ldo >= C && aligned16(out), fn, "out alignment");
@@ -467,14 +436,14 @@ static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const 
     if (ppb < min_ppb) ppb = min_ppb;
     chunks = (HWo + ppb - 1) / ppb;
     GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
-    const size_t lds = (size_t)C * 2 * sizeof(float);
+    const size_t lds = (size_t)C * 2 * sizeof(float) + (size_t)G * 2 * sizeof(double);
     const int silu = (flags & ND_GN_SILU) ? 1 : 0;
     if (pool)
         hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
-                           gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
+                           nchunks, gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
     else
         hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
-                           gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
+                           nchunks, gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
     return check_launch(fn);
 }
 
@@ -482,30 +451,29 @@ static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const 
 
 using namespace nd;
 
-extern "C" int64_t nd_groupnorm_stats_workspace_bytes(int NI, int HW, int C, int G, int dtype) {
-    if (NI <= 0 || HW <= 0 || C <= 0 || G <= 0 || (dtype != ND_DT_F32 && dtype != ND_DT_BF16)) return ND_E_ARG;
+extern "C" int nd_groupnorm_stats_blocks(int NI, int HW, int C, int dtype) {
+    if (NI <= 0 || HW <= 0 || C <= 0 || (dtype != ND_DT_F32 && dtype != ND_DT_BF16)) return ND_E_ARG;
     int QX, PY, ppb, chunks;
     stats_geometry(NI, HW, C / (dtype == ND_DT_BF16 ? 8 : 4), &QX, &PY, &ppb, &chunks);
-    return (int64_t)(((size_t)NI * 4 + 255) & ~(size_t)255) + (int64_t)NI * chunks * G * 2 * 8;
+    return chunks;
 }
 
 extern "C" int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                                       const float* addvec, int ld_add, double* stats, void* workspace, int NI, int HW,
+                                       const float* addvec, int ld_add, double* partials, int NI, int HW,
                                        int G, int dtype, nd_stream_t stream) {
     const char* fn = "nd_groupnorm_stats_nhwc";
     ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
     int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G, dtype == ND_DT_BF16 ? 8 : 4);
     if (rc) return rc;
-    ND_REQUIRE(stats != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
-    ND_REQUIRE(workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, fn, "workspace must be 256-byte aligned");
+    ND_REQUIRE(partials != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ND_DT_BF16)
-        return launch_stats<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, workspace, NI, HW, G, st);
-    return launch_stats<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, workspace, NI, HW, G, st);
+        return launch_stats<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, NI, HW, G, st);
+    return launch_stats<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, NI, HW, G, st);
 }
 
 extern "C" int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                                       const float* addvec, int ld_add, const double* stats,
+                                       const float* addvec, int ld_add, const double* partials, int nblocks,
                                        const float* gamma, const float* beta,
                                        const float* scale, const float* shift, int ld_ss,
                                        void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,
@@ -514,26 +482,26 @@ extern "C" int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const v
     ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
     int rc = check_src(fn, x0, C0, ldx0, x1, C1, ldx1, G, dtype == ND_DT_BF16 ? 8 : 4);
     if (rc) return rc;
-    ND_REQUIRE(stats && gamma && beta && out && NI > 0 && H > 0 && W > 0, fn, "bad arguments");
+    ND_REQUIRE(partials && nblocks > 0 && gamma && beta && out && NI > 0 && H > 0 && W > 0, fn, "bad arguments");
     ND_REQUIRE((scale == nullptr) == (shift == nullptr), fn, "scale and shift go together");
     if (flags & ND_GN_POOL2) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "POOL2 needs even H, W");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ND_DT_BF16)
-        return launch_apply<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, gamma, beta, scale, shift,
-                                    ld_ss, out, ldo, NI, H, W, G, eps, flags, st);
-    return launch_apply<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, stats, gamma, beta, scale, shift, ld_ss,
-                               out, ldo, NI, H, W, G, eps, flags, st);
+        return launch_apply<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, nblocks, gamma, beta, scale,
+                                    shift, ld_ss, out, ldo, NI, H, W, G, eps, flags, st);
+    return launch_apply<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, nblocks, gamma, beta, scale, shift,
+                               ld_ss, out, ldo, NI, H, W, G, eps, flags, st);
 }
 
-extern "C" int nd_groupnorm_coeffs(const double* stats, const float* gamma, const float* beta, const float* scale,
-                                   const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
-                                   int NI, int C, int HW, int G, float eps, nd_stream_t stream) {
+extern "C" int nd_groupnorm_coeffs(const double* stats, int nblocks, const float* gamma, const float* beta,
+                                   const float* scale, const float* shift, int ld_ss, float* coefA, float* coefB,
+                                   int ld_coef, int NI, int C, int HW, int G, float eps, nd_stream_t stream) {
     const char* fn = "nd_groupnorm_coeffs";
-    ND_REQUIRE(stats && gamma && beta && coefA && coefB && NI > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, fn,
-               "bad arguments");
+    ND_REQUIRE(stats && nblocks > 0 && gamma && beta && coefA && coefB && NI > 0 && C > 0 && HW > 0 && G > 0 && G <= 128 &&
+               C % G == 0, fn, "bad arguments");
     ND_REQUIRE((scale == nullptr) == (shift == nullptr) && ld_coef >= C, fn, "scale/shift go together; ld_coef >= C");
-    hipLaunchKernelGGL(gn_coeffs_kernel, dim3((C + 127) / 128, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
-                       stats, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef, C, HW, G, eps);
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3((C + 255) / 256, NI), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       stats, nblocks, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef, C, HW, G, eps);
     return check_launch(fn);
 }
 

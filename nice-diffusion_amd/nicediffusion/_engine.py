@@ -71,7 +71,7 @@ class Act:
 class Normed:
     """GroupNorm output that has not been materialised: the consumer conv applies ``x * A + B`` (+SiLU) while loading.
     The conv emits nd_groupnorm_coeffs (fp32 [NI][C] A/B) first, or falls back to the explicit apply kernel."""
-    __slots__ = ('src', 'src2', 'C', 'silu', 'norm', 'scale_ptr', 'shift_ptr', 'ld_ss', 'slot')
+    __slots__ = ('src', 'src2', 'C', 'silu', 'norm', 'scale_ptr', 'shift_ptr', 'ld_ss', 'slot', 'nblk')
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -164,7 +164,7 @@ class UNetPlan:
         self.y_in = torch.zeros(NI, dtype=torch.int64, device=dev) if model.conditional else None
         self.out = torch.empty(NI * R * R * self.Cout_p, **f32)
         self._gn_slots = 0
-        self._gn_ws_bytes = 256  # GroupNorm statistics workspace (tickets + per-block partials), shared by all norms
+        self._gn_doubles = 0     # float64 words of GroupNorm partial statistics ([NI][blocks][32][2] per norm)
         self._cs_floats = 0     # fp32 words of partial output statistics (see conv(want_stats=True))
         self.taps = []          # (module name, number of ops emitted when its output is complete, Act): debug hook
         _load_tune_cache()
@@ -248,7 +248,7 @@ class UNetPlan:
                 coefB = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 self.keep += [coefA, coefB]
                 self._emit(self.lib.nd_groupnorm_coeffs,
-                           [('gnstats', nm.slot), nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(),
+                           [('gnstats', nm.slot), nm.nblk, nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(),
                             nm.scale_ptr, nm.shift_ptr, nm.ld_ss, coefA.data_ptr(), coefB.data_ptr(), nm.C, nm.src.NI,
                             nm.C, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS], 'gn.coeffs')
                 gn = [coefA.data_ptr(), coefB.data_ptr(), nm.C]
@@ -300,7 +300,7 @@ class UNetPlan:
         """Fallback for consumers that cannot fuse the GroupNorm affine: write the normalised tensor."""
         s2 = (None, 0, 0) if nm.src2 is None else (nm.src2.ptr, nm.src2.C, nm.src2.ld)
         out = self._new(nm.src.NI, nm.src.H, nm.src.W, nm.C)
-        args = [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', nm.slot),
+        args = [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', nm.slot), nm.nblk,
                 nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr,
                 nm.ld_ss, out.ptr, out.ld, nm.src.NI, nm.src.H, nm.src.W, GN_GROUPS, GN_EPS,
                 _hip.GN_SILU if nm.silu else 0, self.dt]
@@ -466,32 +466,33 @@ class UNetPlan:
         """GroupNorm(32) of src (concatenated with src2).  Emits the statistics pass and the coefficient kernel and
         returns a ``Normed`` (applied by the consuming conv's loader); with ``pool`` the activated tensor is average
         pooled, which needs the explicit apply kernel, and an Act is returned."""
-        slot = self._gn_slots
-        self._gn_slots += 1
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
-        if src.cs is not None and (src2 is None or src2.cs is not None):
+        from_conv = src.cs is not None and (src2 is None or src2.cs is not None)
+        nblk = 1 if from_conv else self.lib.nd_groupnorm_stats_blocks(NI, H * W, C, self.dt)
+        assert nblk > 0
+        slot = self._gn_doubles                       # float64 offset of this norm's partials [NI][nblk][32][2]
+        self._gn_doubles += NI * nblk * GN_GROUPS * 2
+        self._gn_slots += 1
+        if from_conv:
             self._emit(self.lib.nd_groupnorm_stats_from_partials,
                        [src.cs[0], src.C, src.cs[1], None if src2 is None else src2.cs[0], 0 if src2 is None else src2.C,
                         0 if src2 is None else src2.cs[1], ('gnstats', slot), NI, GN_GROUPS], label + '.stats_from_partials')
         else:
-            ws = self.lib.nd_groupnorm_stats_workspace_bytes(NI, H * W, C, GN_GROUPS, self.dt)
-            assert ws > 0
-            self._gn_ws_bytes = max(self._gn_ws_bytes, ws)
-            stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), ('gnws', 0), NI, H * W,
-                          GN_GROUPS, self.dt]
+            stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS,
+                          self.dt]
             self._emit(self.lib.nd_groupnorm_stats_nhwc, stats_args, label + '.stats')
         if pool:
             out = self._new(NI, H // 2, W // 2, C)
             flags = (_hip.GN_SILU if silu else 0) | _hip.GN_POOL2
-            apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot),
+            apply_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), nblk,
                           norm.weight.detach().data_ptr(), norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss,
                           out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS, flags, self.dt]
             self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
             return out
         return Normed(src=src, src2=src2, C=C, silu=silu, norm=norm, scale_ptr=scale_ptr, shift_ptr=shift_ptr,
-                      ld_ss=ld_ss, slot=slot)
+                      ld_ss=ld_ss, slot=slot, nblk=nblk)
 
     # ------------------------------------------------------------------------------------------------ build
     def _build(self):
@@ -568,27 +569,19 @@ class UNetPlan:
                   out=out_act, label='conv3x3')
         self._release(x_cur)
 
-        # ---- GroupNorm statistics arena (float64 [slots][NI][32][2], fully written by every forward) and the statistics
-        #      workspace: NI int32 tickets (zeroed at the start of every run; the kernels leave them zero) + partials
-        n_gn = max(1, self._gn_slots) * NI * GN_GROUPS * 2
-        self.gn_stats = torch.zeros(n_gn, dtype=torch.float64, device=dev)
-        slot_bytes = NI * GN_GROUPS * 2 * 8
+        # ---- GroupNorm partial-statistics arena (float64; per norm [NI][blocks][32][2], fully written by every forward:
+        #      nothing to zero, no atomics)
+        self.gn_stats = torch.zeros(max(64, self._gn_doubles), dtype=torch.float64, device=dev)
         base = self.gn_stats.data_ptr()
-        self.gn_ws = torch.zeros((self._gn_ws_bytes + 7) // 8, dtype=torch.float64, device=dev)
-        assert self.gn_ws.data_ptr() % 256 == 0
-        self.gn_tickets = self.gn_ws[:(NI * 4 + 7) // 8]
-        ws_base = self.gn_ws.data_ptr()
         # partial output statistics written by the position-split convs (fully rewritten every forward)
         self.ch_partials = torch.zeros(max(4, self._cs_floats), dtype=torch.float32, device=dev)
         cs_base = self.ch_partials.data_ptr()
 
         def bind(a):
             if isinstance(a, tuple) and a and a[0] == 'gnstats':
-                return base + a[1] * slot_bytes
+                return base + a[1] * 8
             if isinstance(a, tuple) and a and a[0] == 'chpart':
                 return cs_base + a[1] * 4
-            if isinstance(a, tuple) and a and a[0] == 'gnws':
-                return ws_base
             return a
         bound = []
         for fn, args, label in self.ops:
@@ -773,7 +766,6 @@ class UNetPlan:
         """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_tickets.zero_()
         for fn, args, label in self.ops:
             rc = fn(*args, stream)
             if rc != 0:
@@ -785,7 +777,6 @@ class UNetPlan:
         Buffers are recycled by later launches, so each output is copied out right after its last producing launch."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_tickets.zero_()
         got, k = {}, 0
         for idx, (fn, args, label) in enumerate(self.ops):
             rc = fn(*args, stream)
@@ -805,7 +796,6 @@ class UNetPlan:
         launch: the plan's meta (label, entry point, flops, conv variant) plus ``ms``."""
         self._require_current_device()
         stream = self._stream()
-        self.gn_tickets.zero_()
         evs = []
         for fn, args, label in self.ops:
             a = torch.cuda.Event(enable_timing=True)

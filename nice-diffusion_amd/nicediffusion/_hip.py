@@ -41,12 +41,12 @@ SIGNATURES = {
     'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     'nd_conv3x3_winograd_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                        _i, _i, _i, _i, _i, _vp, _vp],
-    'nd_groupnorm_coeffs': [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    'nd_groupnorm_coeffs': [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _vp],
-    'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    'nd_groupnorm_apply_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
+    'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    'nd_groupnorm_apply_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i,
                                 _i, _i, _i, _i, _f, _i, _i, _vp],
     'nd_conv_bf16_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                           _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -74,7 +74,7 @@ _SPECIAL = {
     'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
     'nd_conv_bf16_num_variants': ([], _i),
     'nd_conv_bf16_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
-    'nd_groupnorm_stats_workspace_bytes': ([_i, _i, _i, _i, _i], _i64),
+    'nd_groupnorm_stats_blocks': ([_i, _i, _i, _i], _i),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_winograd_stats_variant': ([], _i),

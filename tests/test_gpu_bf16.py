@@ -199,11 +199,11 @@ def test_conv_bf16_long_k_full_size_layer():
 
 
 def gn_stats(xd, C0, x1d, C1, B, HW, dtype):
-    stats = torch.full((B * 64,), float('nan'), dtype=torch.float64, device=DEV)
-    ws = torch.zeros((lib().nd_groupnorm_stats_workspace_bytes(B, HW, C0 + C1, 32, dtype) + 7) // 8, dtype=torch.float64, device=DEV)
+    nb = lib().nd_groupnorm_stats_blocks(B, HW, C0 + C1, dtype)
+    part = torch.full((B * nb * 64,), float('nan'), dtype=torch.float64, device=DEV)
     _hip.check(lib().nd_groupnorm_stats_nhwc(xd.data_ptr(), C0, C0, None if x1d is None else x1d.data_ptr(), C1, C1, None, 0,
-                                             stats.data_ptr(), ws.data_ptr(), B, HW, 32, dtype, st()))
-    return stats
+                                             part.data_ptr(), B, HW, 32, dtype, st()))
+    return part, nb
 
 
 @pytest.mark.parametrize('B,C0,C1,H,W', [(2, 64, 0, 16, 16), (3, 192, 64, 8, 8), (2, 256, 0, 64, 64), (1, 1024, 1024, 8, 8)])
@@ -222,9 +222,9 @@ def test_groupnorm_bf16(B, C0, C1, H, W, mode):
     if mode == 'pool':
         ref = F.avg_pool2d(ref, 2, 2)
     xad, xbd = nhwc_bf(xa), (nhwc_bf(xb) if C1 else None)
-    stats = gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16)
-    assert torch.equal(stats, gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16))          # reproducible bits
-    s = stats.cpu().view(B, 32, 2)
+    stats, nb = gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16)
+    assert torch.equal(stats, gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16)[0])          # reproducible bits
+    s = stats.cpu().view(B, nb, 32, 2).sum(1)
     xg = x.double().view(B, 32, -1)
     assert torch.allclose(s[..., 0], xg.sum(-1), rtol=1e-12, atol=1e-9)
     assert torch.allclose(s[..., 1], (xg * xg).sum(-1), rtol=1e-12, atol=1e-9)
@@ -233,7 +233,7 @@ def test_groupnorm_bf16(B, C0, C1, H, W, mode):
     p = lambda t: None if t is None else t.data_ptr()
     sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
     gd, bd = gamma.to(DEV), beta.to(DEV)
-    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, None, 0, stats.data_ptr(), gd.data_ptr(),
+    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, None, 0, stats.data_ptr(), nb, gd.data_ptr(),
                                              bd.data_ptr(), p(sc), p(sh), C, out.data_ptr(), C, B, H, W, 32, 1e-5,
                                              _hip.GN_SILU | (_hip.GN_POOL2 if mode == 'pool' else 0), _hip.DT_BF16, st()))
     got = from_nhwc(out, B, Ho, Wo, C)

@@ -46,16 +46,22 @@ def pack_w(w):      # [N,C,k,k] or [N,C] cpu -> MFMA-fragment order on the devic
 
 
 def gn_stats(x0, C0, ld0, x1, C1, ld1, add, ld_add, B, HW, dtype=_hip.DT_F32, G=32):
-    """nd_groupnorm_stats_nhwc with a freshly allocated workspace; the statistics buffer starts as NaN (the kernel must
-    write every entry) and the tickets must be left zero."""
-    stats = torch.full((B * G * 2,), float('nan'), dtype=torch.float64, device=DEV)
-    nbytes = lib().nd_groupnorm_stats_workspace_bytes(B, HW, C0 + C1, G, dtype)
-    assert nbytes > 0
-    ws = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=DEV)
-    _hip.check(lib().nd_groupnorm_stats_nhwc(x0, C0, ld0, x1, C1, ld1, add, ld_add, stats.data_ptr(), ws.data_ptr(), B, HW,
-                                             G, dtype, st()))
-    assert not ws.view(torch.int32)[:B].any(), 'tickets not reset'
-    return stats
+    """nd_groupnorm_stats_nhwc -> (partials [B][nblocks][G][2] float64 on the device, nblocks).  The buffer starts as NaN:
+    the kernel must write every entry (nothing is zeroed or accumulated)."""
+    nb = lib().nd_groupnorm_stats_blocks(B, HW, C0 + C1, dtype)
+    assert nb > 0
+    part = torch.full((B * nb * G * 2,), float('nan'), dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_nhwc(x0, C0, ld0, x1, C1, ld1, add, ld_add, part.data_ptr(), B, HW, G, dtype, st()))
+    return part, nb
+
+
+def gn_sums(part, nb, B, G=32):
+    """[B][G][2] group sums: the partials added in block order (what the consumer kernels do)."""
+    p = part.view(B, nb, G, 2).cpu()
+    acc = torch.zeros(B, G, 2, dtype=torch.float64)
+    for k in range(nb):
+        acc += p[:, k]
+    return acc
 
 
 def test_arch_and_version():
@@ -232,10 +238,10 @@ def test_conv_with_fused_groupnorm(silu):
     w3, w1, b = rnd(Cout, C, 3, 3, seed=7, scale=0.05), rnd(Cout, C, seed=8, scale=0.05), rnd(Cout, seed=9)
     ref3, ref1 = F.conv2d(h, w3, b, padding=1), F.conv2d(h, w1[:, :, None, None], b)
     xad, xbd, bd = nhwc(xa), nhwc(xb), b.to(DEV)
-    stats = gn_stats(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, None, 0, B, H * W)
+    stats, nb = gn_stats(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, None, 0, B, H * W)
     gd, btd, scd, shd = gamma.to(DEV), beta.to(DEV), scale.to(DEV), shift.to(DEV)
     cA, cB = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
-    _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), gd.data_ptr(), btd.data_ptr(), scd.data_ptr(), shd.data_ptr(), C,
+    _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), nb, gd.data_ptr(), btd.data_ptr(), scd.data_ptr(), shd.data_ptr(), C,
                                          cA.data_ptr(), cB.data_ptr(), C, B, C, H * W, 32, 1e-5, st()))
     flags = _hip.CONV_GN_SILU if silu else 0
     wd3, wd1, wq = pack_w(w3), pack_w(w1), pack_wino(w3)
@@ -306,19 +312,19 @@ def test_groupnorm(B, C0, C1, H, W, mode):
     xbd = nhwc(xb) if C1 else None
     addd = add.to(DEV) if mode == 'addvec' else None
     p = lambda t: None if t is None else t.data_ptr()
-    stats = gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W)
-    # no floating-point atomics: a second launch gives the same bits
-    assert torch.equal(stats, gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W))
+    stats, nb = gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W)
+    # no atomics: a second launch gives the same bits
+    assert torch.equal(stats, gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, B, H * W)[0])
     sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
     Ho, Wo = (H // 2, W // 2) if mode == 'pool' else (H, W)
     out = torch.empty(B * Ho * Wo * C, device=DEV)
     flags = (0 if mode == 'plain' else _hip.GN_SILU) | (_hip.GN_POOL2 if mode == 'pool' else 0)
     gd, bd = gamma.to(DEV), beta.to(DEV)
-    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(),
+    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, p(addd), C, stats.data_ptr(), nb,
                                              gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C, out.data_ptr(), C, B, H, W, 32,
                                              1e-5, flags, _hip.DT_F32, st()))
     # statistics themselves (float64 sums)
-    s = stats.cpu().view(B, 32, 2)
+    s = gn_sums(stats, nb, B)
     xg = xin.double().view(B, 32, -1)
     assert torch.allclose(s[..., 0], xg.sum(-1), rtol=1e-12, atol=1e-9)
     assert torch.allclose(s[..., 1], (xg * xg).sum(-1), rtol=1e-12, atol=1e-9)
@@ -586,12 +592,12 @@ def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
         rows = mbi.value * 4
         a = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
         _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
-        b2 = gn_stats(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, B, H * W)
+        b2 = gn_sums(*gn_stats(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, B, H * W), B).flatten().to(DEV)
         assert ((a - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
         # two-source (concatenated) form vs the statistics kernel on the concatenation [out | out]
         a2 = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
         _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, ps.data_ptr(), Cout, rows, a2.data_ptr(), B, 32, st()))
-        b3 = gn_stats(out.data_ptr(), Cout, Cout, out.data_ptr(), Cout, Cout, None, 0, B, H * W)
+        b3 = gn_sums(*gn_stats(out.data_ptr(), Cout, Cout, out.data_ptr(), Cout, Cout, None, 0, B, H * W), B).flatten().to(DEV)
         assert ((a2 - b3).abs() / b3.abs().clamp(min=1.0)).max().item() < 1e-5
     # ldo must equal N
     rc = lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,

@@ -228,16 +228,16 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and 'null' in _hip.last_error()
     rc = lib.nd_attention_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)
     assert rc == -1 and 'multiple of 8' in _hip.last_error()
-    rc = lib.nd_groupnorm_stats_nhwc(16, 30, 32, None, 0, 0, None, 0, 16, None, 1, 4, 32, _hip.DT_F32, None)
+    rc = lib.nd_groupnorm_stats_nhwc(16, 30, 32, None, 0, 0, None, 0, 16, 1, 4, 32, _hip.DT_F32, None)
     assert rc == -1
-    rc = lib.nd_groupnorm_stats_nhwc(16, 32, 32, None, 0, 0, None, 0, 16, None, 1, 4, 32, 7, None)
+    rc = lib.nd_groupnorm_stats_nhwc(16, 32, 32, None, 0, 0, None, 0, 16, 1, 4, 32, 7, None)
     assert rc == -1 and 'dtype' in _hip.last_error()
     rc = lib.nd_conv_bf16_nhwc(16, 12, 16, None, 0, 0, 16, None, None, 0, None, 0, 16, 32, 1, 8, 8, 32, 3, 0, -1, None)
     assert rc == -1 and 'multiples of 8' in _hip.last_error()
     rc = lib.nd_attention_bf16_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)
     assert rc == -1 and 'multiple of 8' in _hip.last_error()
     assert lib.nd_conv_bf16_weight_elems(96, 70, 3) == (2 + 1) * 3 * 9 * 4 * 512      # 70 ch -> 2 chunks of 64 (+1 zero chunk)
-    assert lib.nd_groupnorm_stats_workspace_bytes(64, 4096, 192, 32, _hip.DT_F32) > 64 * 4
+    assert 1 <= lib.nd_groupnorm_stats_blocks(64, 4096, 192, _hip.DT_F32) <= 32 and lib.nd_groupnorm_stats_blocks(2, 64, 64, _hip.DT_BF16) >= 1
 
 
 def test_start_image_resize_follows_cv2_linear_semantics(tmp_path):

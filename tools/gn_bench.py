@@ -14,12 +14,12 @@ dt = _hip.DT_BF16 if bf16 else _hip.DT_F32
 lib = _hip.load(); st = torch.cuda.current_stream().cuda_stream
 x = torch.randn(NI * H * W * C, device='cuda').to(torch.bfloat16 if bf16 else torch.float32); out = torch.empty_like(x)
 g = torch.ones(C, device='cuda'); b = torch.zeros(C, device='cuda')
-stats = torch.zeros(NI * 64, dtype=torch.float64, device='cuda')
-ws = torch.zeros((lib.nd_groupnorm_stats_workspace_bytes(NI, H * W, C, 32, dt) + 7) // 8, dtype=torch.float64, device='cuda')
+nb = lib.nd_groupnorm_stats_blocks(NI, H * W, C, dt)
+stats = torch.zeros(NI * nb * 64, dtype=torch.float64, device='cuda')
 def f_stats():
-    assert lib.nd_groupnorm_stats_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), ws.data_ptr(), NI, H * W, 32, dt, st) == 0
+    assert lib.nd_groupnorm_stats_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), NI, H * W, 32, dt, st) == 0
 def f_apply():
-    assert lib.nd_groupnorm_apply_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), g.data_ptr(), b.data_ptr(), None, None, 0, out.data_ptr(), C, NI, H, W, 32, 1e-5, 1, dt, st) == 0
+    assert lib.nd_groupnorm_apply_nhwc(x.data_ptr(), C, C, None, 0, 0, None, 0, stats.data_ptr(), nb, g.data_ptr(), b.data_ptr(), None, None, 0, out.data_ptr(), C, NI, H, W, 32, 1e-5, 1, dt, st) == 0
 def t(fn):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
