@@ -109,7 +109,7 @@ def kernel_breakdown(model, batch, reps=2):
 
 def _traffic_table():
     """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/r02_pmc_shapes.json:
-    one entry per (kernel kind, variant, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
+    one entry per (kernel kind, variant, ksize, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
     inside this process, so the table is regenerated by that script and looked up by the shapes actually launched."""
     try:
         return json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_shapes.json')))
@@ -160,7 +160,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         missing = 0
         for r in g['rows']:
             NI, H, W, Cin, N = r['shape']
-            rec = tab.get('{}:{}:{}:{}:{}:{}:{}'.format(kind, var, NI, H, W, Cin, N))
+            rec = tab.get('{}:{}:k{}:{}:{}:{}:{}:{}'.format(kind, var, ksize, NI, H, W, Cin, N))
             alg = esize * (NI * H * W * (Cin + N) + ksize * ksize * Cin * N)
             if rec is None:
                 missing += 1

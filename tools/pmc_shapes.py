@@ -6,7 +6,7 @@
 Inputs are the rocprofv3 output directories of separate --pmc passes over tools/pmc_forward.py (tools/pmc_shapes.sh runs
 them): FETCH_SIZE, WRITE_SIZE and optionally GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES.  The
 conv dispatches of the last `reps` forwards are matched, in order, with the plan's launch list, and averaged per key
-    kind:variant:NI:H:W:Cin:N
+    kind:variant:k<ksize>:NI:H:W:Cin:N
 HBM bytes per launch = FETCH_SIZE [KiB] x 1024 x 2 (gfx950 counts 128-byte read requests as 64 bytes:
 MI355X_MICROARCH.md, HBM section) + WRITE_SIZE [KiB] x 1024.  bench.py looks its dominant kernel's shapes up here."""
 import collections
@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc')
 CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino_kernel', 'conv_mfma_kernel', 'gemm_stream_kernel',
-                'conv_bf16_kernel')
+                'conv_bf16_kernel', 'conv_bf16w_kernel')
 
 
 def dispatches(d):
@@ -55,7 +55,7 @@ def main():
             m = convs[j % len(convs)]
             kind, var = m['variant'] if m.get('variant') else ('direct', -1)
             shape = m.get('shape') or [0, 0, 0, 0, 0]
-            key = '{}:{}:{}'.format(kind, var, ':'.join(str(v) for v in shape))
+            key = '{}:{}:k{}:{}'.format(kind, var, m.get('ksize') or 1, ':'.join(str(v) for v in shape))
             e = per_key.setdefault(key, dict(kernel=kname.split('(')[0], label=m['label'], ksize=m.get('ksize'), flops=m['flops'],
                                              n=collections.defaultdict(int), sums=collections.defaultdict(float)))
             assert e['kernel'] == kname.split('(')[0], 'dispatch order does not match the plan at {}: {} vs {}'.format(
@@ -70,7 +70,7 @@ def main():
 
     def key_of(m):
         kind, var = m['variant'] if m.get('variant') else ('direct', -1)
-        return '{}:{}:{}'.format(kind, var, ':'.join(str(v) for v in (m.get('shape') or [0, 0, 0, 0, 0])))
+        return '{}:{}:k{}:{}'.format(kind, var, m.get('ksize') or 1, ':'.join(str(v) for v in (m.get('shape') or [0, 0, 0, 0, 0])))
     counts = collections.Counter(key_of(m) for m in convs)
     out = {}
     tot_h = tot_a = 0.0
@@ -78,7 +78,7 @@ def main():
         avg = {c: e['sums'][c] / e['n'][c] for c in e['sums']}
         rec = dict(kernel=e['kernel'], label=e['label'], launches_per_forward=counts[key],
                    duration_us=round(avg.get('_us', 0.0), 1), flops=e['flops'])
-        NI, H, W, Cin, N = [int(v) for v in key.split(':')[2:]]
+        NI, H, W, Cin, N = [int(v) for v in key.split(':')[3:]]
         k = e['ksize'] or 1
         rec['algorithmic_bytes'] = esize * (NI * H * W * (Cin + N) + k * k * Cin * N)
         if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg and rec['algorithmic_bytes'] > 0:
@@ -111,7 +111,7 @@ def main():
     merged['_totals_' + wl] = {k: dict(hbm_bytes_per_forward=int(v[0]), algorithmic_bytes_per_forward=int(v[1]),
                                        ratio=round(v[0] / v[1], 3), launches=v[2]) for k, v in by_kernel.items()}
     merged['_comment'] = ('Generated by tools/pmc_shapes.sh (rocprofv3 --pmc passes over tools/pmc_forward.py, separate passes for '
-                          'FETCH_SIZE / WRITE_SIZE / SQ counters) and tools/pmc_shapes.py; key = kind:variant:NI:H:W:Cin:N of a '
+                          'FETCH_SIZE / WRITE_SIZE / SQ counters) and tools/pmc_shapes.py; key = kind:variant:k<ksize>:NI:H:W:Cin:N of a '
                           'conv launch IN the forward; hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x '
                           '1024 per launch; algorithmic_bytes = esize x (input + output elements + weights).')
     json.dump(merged, open(path, 'w'), indent=1, sort_keys=True)
