@@ -134,6 +134,8 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
  *   ND_CONV_OUT_F32 `out` is float* and receives the fp32 accumulators (the UNet's last conv, feeding the fp32 sampler
  *   update).  `w` comes from nd_repack_conv_weight_bf16 (fp32 OIHW -> bf16 fragment order
  *   [c64][n tile][tap][k-step][lane][8], nd_conv_bf16_weight_elems elements).  `variant` < 0: cost model.
+ *   gnA/gnB [NI][ld_gn] fp32 | NULL: GroupNorm(+AdaGN)(+SiLU with ND_CONV_GN_SILU) of the INPUT applied by the loader
+ *   (coefficients from nd_groupnorm_coeffs; padding stays zero); needs one image per block (H*W >= the pixel tile).
  * nd_f32_to_bf16_rows: [rows][ldx] fp32 -> [rows][ldo] bf16, channels [C, ldo) zeroed (x_t enters the bf16 UNet).
  * nd_attention_bf16_nhwc: nd_attention_nhwc on bf16 q/k/v (both products on bf16 MFMA, softmax in fp32), bf16 out. */
 int nd_conv_bf16_num_variants(void);
@@ -144,7 +146,8 @@ int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, int C, int6
 int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                       const void* w, const float* bias, const float* rowbias, int ld_rowbias,
                       const void* residual, int ldr, void* out, int ldo,
-                      int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream);
+                      int NI, int H, int W, int N, int ksize, int flags, int variant,
+                      const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream);
 int nd_attention_bf16_nhwc(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int T, int heads, int hd,
                            int q_off, int k_off, int v_off, int head_stride, float scale, nd_stream_t stream);
 

@@ -45,6 +45,11 @@ struct ConvArgsH {
     int thl, twl, nibl;
     int tiles_x, tiles_y, mt, nt, ngroup;
     int silu_out, out_f32;
+    // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels;
+    // one image per block (gn_hw > 0: flat pixel list, image = pixel / gn_hw)
+    const float* gnA;
+    const float* gnB;
+    int ld_gn, gn_silu, gn_hw;
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
@@ -137,11 +142,46 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         }
         return v;
     };
-    auto store_halo_item = [&](int k, int buf, f32x4 v) {
+    // ---- fused GroupNorm (+SiLU) of the input: per-channel coefficients of this block's image in LDS behind the halo
+    //      buffers (A[c] | B[c], c over the padded concatenated channels), applied to a fetched 16-byte item right before
+    //      it is parked in LDS -- padding pixels and channels stay exactly zero, as the reference pads the NORMALISED
+    //      tensor (model.py:190-194).  vmask bit k = item k holds a real pixel.
+    const bool gn = p.gnA != nullptr;
+    float* cfA = smem + 2 * (HP * ROWF);
+    const int CPAD = nchunks * (64 * NSUB);
+    float* cfB = cfA + CPAD;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) vmask |= (gpix[k] >= 0 ? 1u : 0u) << k;
+    if (gn) {
+        const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
+        for (int c = tid; c < CPAD; c += NT) {
+            cfA[c] = (c < Ctot) ? p.gnA[(size_t)gimg * p.ld_gn + c] : 0.f;
+            cfB[c] = (c < Ctot) ? p.gnB[(size_t)gimg * p.ld_gn + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    auto gn_xform = [&](f32x4 raw, int ch, bool valid) -> f32x4 {
+        if (!gn || !valid) return raw;
+        const int c = ch * (64 * NSUB) + (hslot << 3);
+        if (c >= Ctot) return raw;
+        const bf16x8 xv = as_bf16x8(raw);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cfA + c), a1 = *reinterpret_cast<const f32x4*>(cfA + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(cfB + c), b1 = *reinterpret_cast<const f32x4*>(cfB + c + 4);
+        union { f32x4 f; bf16x8 h; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (float)xv[e] * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+            if (p.gn_silu) v = fast_silu(v);
+            o.h[e] = (__bf16)v;
+        }
+        return o.f;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v, int ch) {
         const int hp = hrow0 + k * (NT / SPR);
         if (hp < HP) {
             float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
-            *reinterpret_cast<f32x4*>(dst) = v;
+            *reinterpret_cast<f32x4*>(dst) = gn_xform(v, ch, (vmask >> k) & 1u);
         }
     };
 
@@ -225,7 +265,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 
     // ---- prologue: chunk 0 halo, first weight fragments
 #pragma unroll
-    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
+    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0), 0);
 #pragma unroll
     for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
     __syncthreads();
@@ -285,7 +325,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         const int hp = hrow0 + k * (NT / SPR);
                         if (hp < HP) {
                             float* dst = smem + ((ch + 1) & 1) * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
-                            *reinterpret_cast<f32x4*>(dst) = phb[i];
+                            *reinterpret_cast<f32x4*>(dst) = gn_xform(phb[i], ch + 1, (vmask >> k) & 1u);
                         }
                     }
                 }
@@ -317,14 +357,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 }
                 if (ks >= SD && halo_next) {
 #pragma unroll
-                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - SD) * NBI + i, (ch + 1) & 1, ph[ks - SD][i]);
+                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - SD) * NBI + i, (ch + 1) & 1, ph[ks - SD][i], ch + 1);
                 }
             }
             if (halo_next) {
 #pragma unroll
                 for (int ks = KSTEPS - SD; ks < KSTEPS; ++ks)
 #pragma unroll
-                    for (int i = 0; i < NBI; ++i) store_halo_item(ks * NBI + i, (ch + 1) & 1, ph[ks][i]);
+                    for (int i = 0; i < NBI; ++i) store_halo_item(ks * NBI + i, (ch + 1) & 1, ph[ks][i], ch + 1);
             }
         }
         // halo hand-over: only LDS traffic has to be complete; the weight prefetch stays in flight across the barrier
@@ -884,7 +924,8 @@ extern "C" int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, 
 extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                                  const void* w, const float* bias, const float* rowbias, int ld_rowbias,
                                  const void* residual, int ldr, void* out, int ldo,
-                                 int NI, int H, int W, int N, int ksize, int flags, int variant, nd_stream_t stream) {
+                                 int NI, int H, int W, int N, int ksize, int flags, int variant,
+                                 const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     const char* fn = "nd_conv_bf16_nhwc";
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
@@ -937,6 +978,22 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * 2);
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
+    a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
+    size_t lds_gn = 0;
+    if (gnA) {
+        // one image per block, so that the block's coefficient table in LDS is that image's
+        ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1, fn, "fused GroupNorm: bad coefficient arrays");
+        ND_REQUIRE(!V.ldsw, fn, "fused GroupNorm: not available in the LDS-DMA variants");
+        if (pNI == 1 && pH == 1 && taps == 1 && NI * H * W == pW) {
+            ND_REQUIRE(((long)H * W) % V.bm() == 0, fn, "fused GroupNorm (1x1): H*W must be a multiple of the pixel tile");
+            a.gn_hw = H * W;
+        } else {
+            ND_REQUIRE(tp.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
+        }
+        const int nsub = taps == 9 ? 1 : 2;
+        lds_gn = (size_t)2 * ((a.NC64 + nsub - 1) / nsub) * (64 * nsub) * sizeof(float);
+        ND_REQUIRE(lds_bytes_h(taps, tp.hp) + lds_gn <= 160 * 1024, fn, "fused GroupNorm: LDS budget exceeded");
+    }
     const int grid = a.mt * a.nt;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (V.ldsw) {
@@ -949,6 +1006,6 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
         }
         return fail_arg(fn, "bad variant");
     }
-    const size_t lds = lds_bytes_h(taps, tp.hp);
+    const size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
     return (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
 }

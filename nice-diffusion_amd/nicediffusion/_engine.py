@@ -327,9 +327,33 @@ class UNetPlan:
 
     def _conv_bf16(self, src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label, pad_c_to):
         tmp = None
+        gn = [None, None, 0]
         if isinstance(src, Normed):
-            tmp = self._materialise(src)          # bf16 apply pass (HBM-bound, half the bytes of the fp32 one)
-            src, src2 = tmp, None
+            nm = src
+            up_ = 1 if (flags & _hip.CONV_IN_UP2X) else 0
+            hw = (nm.src.H << up_) * (nm.src.W << up_)
+            fl_ = 2 * nm.src.NI * hw * N * ksize * ksize * nm.C
+            # fused into the conv's loader when a block never spans two images (every tile is <= 256 pixels) and the
+            # launch is big enough to be tuned (ND_FUSE_GN=0 switches the fold off); else the bf16 apply pass
+            # every 256-channel n block re-evaluates the affine (+SiLU) of its input tile, so the fold only pays for
+            # narrow outputs (ND_FUSE_GN_MAXNB n blocks at most)
+            maxnb = int(os.environ.get('ND_FUSE_GN_MAXNB', '2'))
+            if _fuse_gn_mode() >= 1 and hw >= 256 and hw % 256 == 0 and rowbias is None and fl_ >= 2e8 and \
+                    _autotune_enabled() and (N + 255) // 256 <= maxnb:
+                src, src2 = nm.src, nm.src2
+                coefA = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
+                coefB = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
+                self.keep += [coefA, coefB]
+                self._emit(self.lib.nd_groupnorm_coeffs,
+                           [('gnstats', nm.slot), nm.nblk, nm.norm.weight.detach().data_ptr(),
+                            nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr, nm.ld_ss, coefA.data_ptr(),
+                            coefB.data_ptr(), nm.C, nm.src.NI, nm.C, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS], 'gn.coeffs')
+                gn = [coefA.data_ptr(), coefB.data_ptr(), nm.C]
+                if nm.silu:
+                    flags |= _hip.CONV_GN_SILU
+            else:
+                tmp = self._materialise(nm)          # bf16 apply pass (HBM-bound, half the bytes of the fp32 one)
+                src, src2 = tmp, None
         up = 1 if (flags & _hip.CONV_IN_UP2X) else 0
         NI, H, W = src.NI, src.H << up, src.W << up
         if out is None:
@@ -344,9 +368,9 @@ class UNetPlan:
                 wq.data_ptr(), bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N, ksize, flags]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
-        key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None)
-        var = self._pick_bf16(key, fl, head)
-        self._emit(self.lib.nd_conv_bf16_nhwc, head + [var], label, flops=fl, variant=('bf16', var), ksize=ksize,
+        key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
+        var = self._pick_bf16(key, fl, head, gn)
+        self._emit(self.lib.nd_conv_bf16_nhwc, head + [var] + gn, label, flops=fl, variant=('bf16', var), ksize=ksize,
                    shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
@@ -354,7 +378,7 @@ class UNetPlan:
             self._release(tmp)
         return out
 
-    def _pick_bf16(self, key, flops, head):
+    def _pick_bf16(self, key, flops, head, gn):
         """Tile variant for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with ND_AUTOTUNE=0,
         else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per shape."""
         if not _autotune_enabled() or flops < 2e8:
@@ -366,7 +390,7 @@ class UNetPlan:
         fn = self.lib.nd_conv_bf16_nhwc
         best, best_ms = -1, None
         for v in range(self.lib.nd_conv_bf16_num_variants()):
-            args = head + [v]
+            args = head + [v] + gn
             if fn(*args, stream) != 0:
                 continue                                  # this tile shape does not fit the problem
             if not _CLOCK_SETTLED[0]:

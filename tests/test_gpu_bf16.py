@@ -120,7 +120,7 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
             out = torch.full((B * H * W * Cout,), float('nan'), dtype=torch.float32 if f32out else BF, device=DEV)
             rc = lib().nd_conv_bf16_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
                                          out.data_ptr(), Cout, B, H, W, Cout, ksize, _hip.CONV_OUT_F32 if f32out else 0,
-                                         v, st())
+                                         v, None, None, 0, st())
             if rc != 0:
                 assert v >= 0 and 'no tile variant fits' in _hip.last_error(), (v, _hip.last_error())
                 continue
@@ -148,7 +148,7 @@ def test_conv_bf16_fused_options():
     for v in (0, 4, 7, -1):
         out = torch.empty(B * H * W * N, dtype=BF, device=DEV)
         _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
-                                           rbd.data_ptr(), N, resd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, 0, v, st()))
+                                           rbd.data_ptr(), N, resd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, 0, v, None, None, 0, st()))
         err = (from_nhwc(out, B, H, W, N) - ref.float()).abs()
         assert (err <= _tol_bf16(ref.float())).all(), (v, err.max().item())
     # SiLU on the output; 1x1 with a strided output row (ldo > N) and fp32 output
@@ -157,7 +157,7 @@ def test_conv_bf16_fused_options():
     ref1 = F.silu(F.conv2d(q(xa).double(), q(w1).double()[:, :, None, None], b.double())).float()
     out = torch.zeros(B * H * W * (N + 8), dtype=torch.float32, device=DEV)
     _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd1.data_ptr(), bd.data_ptr(), None, 0, None, 0,
-                                       out.data_ptr(), N + 8, B, H, W, N, 1, _hip.CONV_SILU_OUT | _hip.CONV_OUT_F32, -1, st()))
+                                       out.data_ptr(), N + 8, B, H, W, N, 1, _hip.CONV_SILU_OUT | _hip.CONV_OUT_F32, -1, None, None, 0, st()))
     assert (from_nhwc(out, B, H, W, N, N + 8) - ref1).abs().max().item() < 2e-4
     assert not out.view(B, H, W, N + 8)[..., N:].any()
     # nearest-2x upsampled input and residual
@@ -167,14 +167,60 @@ def test_conv_bf16_fused_options():
     xsd, rsd, wd3 = nhwc_bf(xs), nhwc_bf(rs), pack_bf(w3)
     out = torch.empty(B * H * W * N, dtype=BF, device=DEV)
     _hip.check(lib().nd_conv_bf16_nhwc(xsd.data_ptr(), C0, C0, None, 0, 0, wd3.data_ptr(), bd.data_ptr(), None, 0, None, 0,
-                                       out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_IN_UP2X, -1, st()))
+                                       out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_IN_UP2X, -1, None, None, 0, st()))
     err = (from_nhwc(out, B, H, W, N) - ref_up.float()).abs()
     assert (err <= _tol_bf16(ref_up.float())).all()
     ref_r = F.conv2d(q(xa).double(), q(w3).double(), b.double(), padding=1) + F.interpolate(q(rs), scale_factor=2.0, mode='nearest').double()
     _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd3.data_ptr(), bd.data_ptr(), None, 0,
-                                       rsd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_RES_UP2X, -1, st()))
+                                       rsd.data_ptr(), N, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_RES_UP2X, -1, None, None, 0, st()))
     err = (from_nhwc(out, B, H, W, N) - ref_r.float()).abs()
     assert (err <= _tol_bf16(ref_r.float())).all()
+
+
+@pytest.mark.parametrize('ksize,silu', [(3, True), (1, False), (3, False)])
+def test_conv_bf16_fused_groupnorm(ksize, silu):
+    """GroupNorm(+AdaGN)(+SiLU) of a two-source input applied by the conv's loader (coefficients from nd_groupnorm_coeffs)
+    = the explicit bf16 apply pass followed by the plain conv, up to the one bf16 rounding of the normalised tensor that
+    the fused form shares; zero padding must stay zero AFTER normalisation (model.py:190-194)."""
+    B, C0, C1, N, H, W = 2, 64, 32, 96, 16, 16
+    C = C0 + C1
+    xa, xb = rnd(B, C0, H, W, seed=1) * 2 + 0.5, rnd(B, C1, H, W, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.5 + 0.1 * rnd(C, seed=4)       # beta != 0: padding would show up
+    scale, shift = 0.3 * rnd(B, C, seed=5), 0.3 * rnd(B, C, seed=6)
+    w = rnd(N, C, ksize, ksize, seed=7, scale=0.05)
+    b = rnd(N, seed=8)
+    x = q(torch.cat([xa, xb], 1))
+    h = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5) * (1 + scale.double()[:, :, None, None]) \
+        + shift.double()[:, :, None, None]
+    if silu:
+        h = F.silu(h)
+    ref = F.conv2d(q(h.float()).double(), q(w).double(), b.double(), padding=ksize // 2).float()
+    xad, xbd, bd = nhwc_bf(xa), nhwc_bf(xb), b.to(DEV)
+    wd = pack_bf(w if ksize == 3 else w[:, :, 0, 0])
+    stats, nb = gn_stats(xad, C0, xbd, C1, B, H * W, _hip.DT_BF16)
+    gd, btd, scd, shd = gamma.to(DEV), beta.to(DEV), scale.to(DEV), shift.to(DEV)
+    cA, cB = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
+    _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), nb, gd.data_ptr(), btd.data_ptr(), scd.data_ptr(), shd.data_ptr(), C,
+                                         cA.data_ptr(), cB.data_ptr(), C, B, C, H * W, 32, 1e-5, st()))
+    flags = _hip.CONV_GN_SILU if silu else 0
+    ran = 0
+    for v in range(lib().nd_conv_bf16_num_variants()):
+        out = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                     None, 0, out.data_ptr(), N, B, H, W, N, ksize, flags, v, cA.data_ptr(), cB.data_ptr(), C,
+                                     st())
+        if rc != 0:
+            continue            # tile shape does not fit / variant cannot fuse
+        ran += 1
+        err = (from_nhwc(out, B, H, W, N) - ref).abs()
+        # the normalised activations are rounded to bf16 once (as in the unfused path); fp32 vs fp64 coefficient
+        # arithmetic can move a value across a rounding boundary, hence a slightly wider bound than the plain conv
+        assert (err <= 2.0 ** -7 * ref.abs() + 6e-3 * ref.abs().max().clamp(min=1.0)).all(), (v, err.max().item())
+    assert ran >= 4
+    # several images per block are refused (callers materialise the normalised tensor instead)
+    rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
+                                 out.data_ptr(), N, B * 4, 8, 8, N, ksize, flags, 0, cA.data_ptr(), cB.data_ptr(), C, st())
+    assert rc == -1
 
 
 def test_conv_bf16_long_k_full_size_layer():
@@ -190,7 +236,7 @@ def test_conv_bf16_long_k_full_size_layer():
     for v in range(lib().nd_conv_bf16_num_variants()):
         out = torch.empty(B * H * W * N, dtype=torch.float32, device=DEV)
         rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
-                                     None, 0, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_OUT_F32, v, st())
+                                     None, 0, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_OUT_F32, v, None, None, 0, st())
         if rc == 0:
             outs.append((v, from_nhwc(out, B, H, W, N)))
     assert len(outs) >= 6

@@ -232,7 +232,7 @@ def test_argument_validation_without_gpu():
     assert rc == -1
     rc = lib.nd_groupnorm_stats_nhwc(16, 32, 32, None, 0, 0, None, 0, 16, 1, 4, 32, 7, None)
     assert rc == -1 and 'dtype' in _hip.last_error()
-    rc = lib.nd_conv_bf16_nhwc(16, 12, 16, None, 0, 0, 16, None, None, 0, None, 0, 16, 32, 1, 8, 8, 32, 3, 0, -1, None)
+    rc = lib.nd_conv_bf16_nhwc(16, 12, 16, None, 0, 0, 16, None, None, 0, None, 0, 16, 32, 1, 8, 8, 32, 3, 0, -1, None, None, 0, None)
     assert rc == -1 and 'multiples of 8' in _hip.last_error()
     rc = lib.nd_attention_bf16_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)
     assert rc == -1 and 'multiple of 8' in _hip.last_error()

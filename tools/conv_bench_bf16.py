@@ -27,7 +27,7 @@ warm = False
 for v in variants:
     def run():
         return lib.nd_conv_bf16_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0,
-                                     out.data_ptr(), N, NI, H, W, N, ks, 0, v, st)
+                                     out.data_ptr(), N, NI, H, W, N, ks, 0, v, None, None, 0, st)
     if run() != 0:
         print('variant', v, 'n/a:', _hip.last_error())
         continue
