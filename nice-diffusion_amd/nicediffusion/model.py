@@ -6,6 +6,8 @@ checkpoints works), and default initialisation consumes the RNG in the same orde
 same weights.  The modules below only HOLD parameters; the arithmetic of ``forward`` is a plan of ``libnd_hip.so``
 launches over NHWC buffers (see ``_engine.py``).  There is no CPU path: calling the model on CPU tensors raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -171,7 +173,7 @@ class DiffusionModel(nn.Module):
         self.verify_weights = True     # digest the weights on the device before reusing a cached plan
         # arithmetic of the forward: 'fp32' = the reference's (exact fp32 MFMA kernels); 'bf16' = bf16 activations and
         # weights with fp32 accumulation (parameters stay fp32; the cast happens in the plan's weight repack)
-        self.compute_dtype = 'fp32'
+        self.compute_dtype = os.environ.get('ND_COMPUTE_DTYPE', 'fp32')      # e.g. ND_COMPUTE_DTYPE=bf16 scripts/sample.py ...
 
     # -------------------------------------------------------------------------------------------- plan management
     def _residual_blocks(self):
