@@ -440,6 +440,389 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_16x16x32_bf16 (TM, TN count 16-wide tiles; a k-step is 32 channels; weights packed by
+// nd_repack_conv_weight_bf16 with layout 1).  Per flop it moves the same operand bytes as the 32x32x16 form, but the
+// chip holds a higher clock under it (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15x the FLOP/s at equal cycles),
+// and the bf16 convolutions are limited by the clock the chip holds, not by stalls.
+//   A operand (weights)     lane (n = lane & 15, kq = lane >> 4) holds w[n][32*ks + 8*kq + j]
+//   B operand (activations) lane (pixel = lane & 15, kq)        holds x[pixel][32*ks + 8*kq + j] = LDS slot 4*ks + kq
+//   C/D                     lane (pixel = lane & 15): registers 0..3 = output channels 4*kq .. 4*kq + 3
+template <int WM, int WN, int TM, int TN, int TAPS>
+__global__ void __launch_bounds__(WM* WN * 64, 2)
+    conv_bf16s_kernel(const ConvArgsH p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 16;      // TM, TN count 16-wide tiles of v_mfma_f32_16x16x32_bf16
+    constexpr int BN = WN * TN * 16;
+    constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int NSUB = (TAPS == 9) ? 1 : 2;          // 64-channel sub-chunks per LDS chunk
+    constexpr int SPR = 8 * NSUB;                      // 16-byte slots per halo pixel row
+    constexpr int ROWF = 32 * NSUB;                    // 4-byte words per halo pixel row
+    constexpr int KSTEPS = 2 * NSUB;                   // k-steps (32 channels each) per chunk and tap
+    constexpr int STEPS = TAPS * 2;                    // fragments per 64-channel chunk and 16-channel n tile
+    // halo 16-byte items per thread per chunk: 3x3 tiles carry up to 1.5625x their pixels as halo (8x8 maps; fetched in 3 batches,
+    // one per tap row); the 1x1 form has exactly BM rows (fetched one group per k-step)
+    constexpr int NBI = (TAPS == 9) ? (((BM * 25 + 2 * NT - 1) / (2 * NT) + 2) / 3) : ((BM * SPR / NT + KSTEPS - 1) / KSTEPS);
+    constexpr int NBATCH = (TAPS == 9) ? 3 : KSTEPS;
+    constexpr int MAXHI = NBI * NBATCH;
+    static_assert(NT % SPR == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [HP][ROWF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int l15 = lane & 15;      // pixel (B operand column) / output channel (A operand row) inside a 16-wide tile
+    const int kq = lane >> 4;       // which 8 of the k-step's 32 channels this lane holds
+
+    // ---- XCD-aware block -> tile map (see nd_conv_mfma.hip)
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2 * PAD, HW = TW + 2 * PAD;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    // ---- halo descriptors
+    const int hslot = tid % SPR;
+    const int hrow0 = tid / SPR;
+    int gpix[MAXHI];
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) {
+        const int hp = hrow0 + k * (NT / SPR);
+        int g = -1;
+        if (hp < HP) {
+            const int li = hp / HPI;
+            const int rem = hp - li * HPI;
+            const int hy = rem / HW;
+            const int hx = rem - hy * HW;
+            const int img = img0 + li;
+            const int iy = oy0 - PAD + hy, ix = ox0 - PAD + hx;
+            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
+        }
+        gpix[k] = g;
+    }
+
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = (p.NC64 + NSUB - 1) / NSUB;
+
+    auto swz = [](int hp) -> int { return (SPR == 8) ? ((hp >> 1) & 7) : (hp & 15); };
+    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int c = ch * (64 * NSUB) + (hslot << 3);
+#if defined(ND_HABL_NOHALO)      // timing-only ablation: only chunk 0 is ever fetched
+        if (ch > 0) { asm volatile("" :: "v"(g)); return v; }
+#endif
+        if (g >= 0 && c < Ctot) {
+            const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        return v;
+    };
+    // ---- fused GroupNorm (+SiLU) of the input: per-channel coefficients of this block's image in LDS behind the halo
+    //      buffers (A[c] | B[c], c over the padded concatenated channels), applied to a fetched 16-byte item right before
+    //      it is parked in LDS -- padding pixels and channels stay exactly zero, as the reference pads the NORMALISED
+    //      tensor (model.py:190-194).  vmask bit k = item k holds a real pixel.
+    const bool gn = p.gnA != nullptr;
+    float* cfA = smem + 2 * (HP * ROWF);
+    const int CPAD = nchunks * (64 * NSUB);
+    float* cfB = cfA + CPAD;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) vmask |= (gpix[k] >= 0 ? 1u : 0u) << k;
+    if (gn) {
+        const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
+        for (int c = tid; c < CPAD; c += NT) {
+            cfA[c] = (c < Ctot) ? p.gnA[(size_t)gimg * p.ld_gn + c] : 0.f;
+            cfB[c] = (c < Ctot) ? p.gnB[(size_t)gimg * p.ld_gn + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    auto gn_xform = [&](f32x4 raw, int ch, bool valid) -> f32x4 {
+        if (!gn || !valid) return raw;
+        const int c = ch * (64 * NSUB) + (hslot << 3);
+        if (c >= Ctot) return raw;
+        const bf16x8 xv = as_bf16x8(raw);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cfA + c), a1 = *reinterpret_cast<const f32x4*>(cfA + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(cfB + c), b1 = *reinterpret_cast<const f32x4*>(cfB + c + 4);
+        union { f32x4 f; bf16x8 h; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (float)xv[e] * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
+            if (p.gn_silu) v = fast_silu(v);
+            o.h[e] = (__bf16)v;
+        }
+        return o.f;
+    };
+    auto store_halo_item = [&](int k, int buf, f32x4 v, int ch) {
+        const int hp = hrow0 + k * (NT / SPR);
+        if (hp < HP) {
+            float* dst = smem + buf * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+            *reinterpret_cast<f32x4*>(dst) = gn_xform(v, ch, (vmask >> k) & 1u);
+        }
+    };
+
+    // ---- per-lane operand rows
+    int a_hp[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 16 + l15;
+        const int li = m >> (p.thl + p.twl);
+        const int py = (m >> p.twl) & (TH - 1);
+        const int px = m & (TW - 1);
+        a_hp[mi] = li * HPI + py * HW + px;
+    }
+    // weight fragment stream of 16-channel n tile ni: [c64][n16 tile][step][lane][8 bf16]; one fragment = 16 ch x 32 k = 1 KiB
+    const __bf16* bp[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        int ntile = nblk * (BN / 16) + wn * TN + ni;
+        if (ntile > 2 * p.NT32 - 1) ntile = 2 * p.NT32 - 1;      // N tail: results are discarded in the epilogue
+        bp[ni] = p.w + (size_t)ntile * (STEPS * 512) + lane * 8;
+    }
+    const size_t c64_jump = (size_t)(2 * p.NT32 - 1) * (STEPS * 512);
+    int ld_in_c64 = 0;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operand registers.  Weights: ring of RING fragments per n tile, fetched RING-1 k-steps ahead.  Activations: ONE
+    // register set -- the slot of tile mi for the NEXT k-step is re-read right behind the MFMAs that consumed it and has
+    // the other TM-1 tiles' MFMAs (>= 190 cycles) to land; 128 accumulator + 16 + 24 operand registers leave room for
+    // two waves per SIMD.
+    constexpr int RING = (TN >= 4) ? 2 : ((TAPS == 9) ? 3 : 4);      // divides the 6 / 4 unrolled k-steps; k-steps are 32 channels here
+    constexpr int BDIST = RING - 1;
+    f32x4 a_fr[TM], b_fr[RING][TN];
+    // the packed buffer carries a whole zero chunk at the end, so the stream may always run ahead
+    auto advance_b = [&](f32x4 (&dst)[TN]) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#if !defined(ND_HABL_NOB)        // timing-only ablation: weight fragments stay whatever the registers hold
+            dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
+#endif
+            bp[ni] += 512;
+        }
+        if (++ld_in_c64 == STEPS) {
+            ld_in_c64 = 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bp[ni] += c64_jump;
+        }
+    };
+    // one k-step: TM x TN MFMAs; behind tile mi's MFMAs its fragment for the next step is read from LDS word offset
+    // noff[mi] (already swizzled)
+    auto mfma_step = [&](const f32x4 (&bw)[TN], const float* hbuf, const int (&noff)[TM]) {
+        ND_PRIO(1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bw[ni]), as_bf16x8(a_fr[mi]), acc[mi][ni], 0, 0, 0);
+#if !defined(ND_HABL_NOA)        // timing-only ablation: no LDS fragment reads
+            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + noff[mi]);
+#else
+            asm volatile("" :: "v"(noff[mi]));
+#endif
+        }
+#if ND_BF16_SCHED && !defined(ND_HABL_NOA)
+        // pin the interleave: TN MFMAs, then the one LDS read that refills the fragment they consumed (left alone the
+        // scheduler sinks all TM reads behind the last MFMA, so the next step opens waiting for LDS)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
+        ND_PRIO(0);
+    };
+
+    // ---- prologue: chunk 0 halo, first weight fragments
+#pragma unroll
+    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0), 0);
+#pragma unroll
+    for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
+        const bool halo_next = (ch + 1) < nchunks;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int hp = a_hp[mi];
+            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((kq ^ swz(hp)) << 2));
+        }
+        if constexpr (TAPS == 9) {
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                // next chunk's halo arrives in 3 batches of NBI items (one batch per tap row), fetched at the top of the
+                // row and parked in the other LDS buffer after its 6 k-steps (~3000 cycles later)
+                int gs[NBI];
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) {
+                    int g = gpix[i];
+                    g = (dy == 1) ? gpix[NBI + i] : g;
+                    g = (dy == 2) ? gpix[2 * NBI + i] : g;
+                    gs[i] = halo_next ? g : -1;
+                }
+                f32x4 phb[NBI];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tapoff = dy * HW + dx;
+                    const int tapoff_n = (dx < 2) ? tapoff + 1 : ((dy < 2) ? (dy + 1) * HW : 0);
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+                        const int st = dx * 2 + kc;                 // 0 .. 5, compile-time: ring slots are static
+                        advance_b(b_fr[(st + BDIST) % RING]);
+                        if (dx == 0 && kc == 0) {
+#pragma unroll
+                            for (int i = 0; i < NBI; ++i) phb[i] = load_halo_pixel(gs[i], ch + 1);
+                        }
+                        int noff[TM];
+                        {
+                            const int nslot = (((kc + 1) & 1) << 2) | kq;
+                            const int toff = (kc == 1) ? tapoff_n : tapoff;
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi) {
+                                const int hp = a_hp[mi] + toff;     // (after the last step of a chunk this reads stale but
+                                noff[mi] = hp * ROWF + ((nslot ^ swz(hp)) << 2);   //  in-bounds data that is discarded)
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(b_fr[st % RING], hbuf, noff);
+                    }
+                }
+                if (halo_next) {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) {
+                        const int k = dy * NBI + i;      // dy is a run-time value: the item index is plain arithmetic
+                        const int hp = hrow0 + k * (NT / SPR);
+                        if (hp < HP) {
+                            float* dst = smem + ((ch + 1) & 1) * (HP * ROWF) + hp * ROWF + ((hslot ^ swz(hp)) << 2);
+                            *reinterpret_cast<f32x4*>(dst) = gn_xform(phb[i], ch + 1, (vmask >> k) & 1u);
+                        }
+                    }
+                }
+            }
+        } else {
+            // 1x1: KSTEPS k-steps per chunk; the next chunk's rows are fetched one group of NBI per step and parked two
+            // steps later (the last groups behind the loop)
+            f32x4 ph[KSTEPS][NBI];
+            constexpr int SD = 2;      // k-steps between a group's fetch and its LDS store
+            const bool second = (ch * NSUB + 1) < p.NC64;          // the chunk's second 64-channel half holds real channels
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks < 2 || second) {
+                    advance_b(b_fr[(ks + BDIST) % RING]);
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) ph[ks][i] = load_halo_pixel(halo_next ? gpix[ks * NBI + i] : -1, ch + 1);
+                    int noff[TM];
+                    {
+                        const int nstep = (ks + 1) & (KSTEPS - 1);      // wraps to 0 after the last step: discarded
+                        const int nslot = (nstep << 2) | kq;
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) noff[mi] = a_hp[mi] * ROWF + ((nslot ^ swz(a_hp[mi])) << 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(b_fr[ks % RING], hbuf, noff);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) ph[ks][i] = load_halo_pixel(halo_next ? gpix[ks * NBI + i] : -1, ch + 1);
+                }
+                if (ks >= SD && halo_next) {
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) store_halo_item((ks - SD) * NBI + i, (ch + 1) & 1, ph[ks - SD][i], ch + 1);
+                }
+            }
+            if (halo_next) {
+#pragma unroll
+                for (int ks = KSTEPS - SD; ks < KSTEPS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) store_halo_item(ks * NBI + i, (ch + 1) & 1, ph[ks][i], ch + 1);
+            }
+        }
+        // halo hand-over: only LDS traffic has to be complete; the weight prefetch stays in flight across the barrier
+#if !defined(ND_HABL_NOBAR)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
+    }
+#if defined(ND_HABL_NOEPI)
+    if (p.N > 0) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.out)[0] = acc[0][0][1]; return; }
+#endif
+
+    // ---- epilogue: C/D of the 16x16 tile: lane = pixel l15, registers = the 4 consecutive output channels 4*kq .. +3
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = (wm * TM + mi) * 16 + l15;
+        const int li = m >> (p.thl + p.twl);
+        const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+        const int ox = ox0 + (m & (TW - 1));
+        const int img = img0 + li;
+        if (img < p.NI && oy < p.H && ox < p.W) {
+            const size_t opix = (size_t)(img * p.H + oy) * p.W + ox;
+            const float* rb = p.rowbias ? p.rowbias + (size_t)img * p.ld_rowbias : nullptr;
+            const __bf16* rr = nullptr;
+            if (p.res) {
+                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
+                rr = p.res + rp * p.ldr;
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + (wn * TN + ni) * 16 + 4 * kq;
+                if (n + 3 < p.N && vec_ok) {
+                    f32x4 v = acc[mi][ni];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
+                    if (rr) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    if (p.silu_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                    }
+                    if (p.out_f32) {
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + opix * p.ldo + n) = v;
+                    } else {
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.N) {
+                            float v = acc[mi][ni][e];
+                            if (p.bias) v += p.bias[n + e];
+                            if (rb) v += rb[n + e];
+                            if (rr) v += (float)rr[n + e];
+                            if (p.silu_out) v = fast_silu(v);
+                            if (p.out_f32) static_cast<float*>(p.out)[opix * p.ldo + n + e] = v;
+                            else static_cast<__bf16*>(p.out)[opix * p.ldo + n + e] = (__bf16)v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // 3x3 form with BOTH operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write).
 // Ablations of the kernel above put the weight-fragment stream (global -> VGPR per wave, two waves fetching every
 // fragment, in-order vmcnt coupling it to the halo fetches) at 1.4x of the run time.  Here a block's weight fragments
@@ -517,16 +900,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         gpx[k] = g;
         hsl[k] = ((U & 7) ^ swz(hp)) << 3;
     }
-    auto issue_halo = [&](int k, int ch, int buf) {     // wave-uniform guard: pieces past the buffer are not issued
+    // Exactly ONE halo DMA per wave and call, so that the in-flight count per tap is uniform: pieces past the buffer
+    // (wave-uniform) become a 16-byte-per-lane copy of zeros into a per-wave scratch piece behind the weight ring.
+    float* scratch = wring + 2 * STAGE_W + wave * 256;
+    auto issue_halo = [&](int k, int ch, int buf, bool real) {
         const int u = k * NW + wave;
-        if (u < NPIECE) {
-            const int c = ch * 64 + hsl[k];
-            const int g = gpx[k];
-            const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
-                                           : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
-            src = (g >= 0 && c < Ctot) ? src : zero16;
-            ND_GLDS16H(src, smem + buf * HBUF_W + u * 256);
-        }
+        const bool live = real && u < NPIECE;
+        const int c = ch * 64 + hsl[k];
+        const int g = gpx[k];
+        const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
+                                       : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
+        src = (live && g >= 0 && c < Ctot) ? src : zero16;
+        ND_GLDS16H(src, live ? (smem + buf * HBUF_W + u * 256) : scratch);
     };
 
     // ---- weight DMAs: fragment f = j * NW + wave of a tap stage = (k-step f / NTB, n tile f % NTB)
@@ -569,7 +954,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     const int nchunks = p.NC64;
     // ---- prologue: chunk 0 halo (all pieces), tap 0 weights
 #pragma unroll
-    for (int k = 0; k < 9; ++k) issue_halo(k, 0, 0);
+    for (int k = 0; k < 9; ++k) issue_halo(k, 0, 0, true);
     issue_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -589,7 +974,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 {
                     const int ntap = (tap == 8) ? 0 : tap + 1;
                     issue_w(ch + (tap == 8 ? 1 : 0), ntap, (gt + 1) & 1);
-                    if (ch + 1 < nchunks) issue_halo(tap, ch + 1, (ch + 1) & 1);
+                    issue_halo(tap, ch + 1, (ch + 1) & 1, ch + 1 < nchunks);       // the YOUNGEST operation of the tap
                 }
                 const int tapoff = dy * HW + dx;
                 // this tap's first fragments
@@ -631,8 +1016,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                     }
                     ND_PRIO(0);
                 }
-                // publish: every DMA this wave issued during the tap has landed, every LDS read of the tap is done
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // publish: the weight DMAs this wave issued during the tap have landed (vmcnt(1): all but the youngest
+                // operation, this tap's halo piece, which is older than everything the NEXT tap's wait leaves in flight --
+                // so a halo piece has two taps to arrive and only the chunk's last tap, below, waits for all of them);
+                // every LDS read of the tap is done
+                if (tap == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
@@ -720,6 +1109,25 @@ __global__ void pack_conv_weight_bf16_kernel(const float* w, __bf16* out, int N,
     }
 }
 
+// layout 1 (v_mfma_f32_16x16x32_bf16 fragments):
+//   out[((((c64*NT16 + nt16)*taps + tap)*2 + ks)*64 + lane)*8 + j] = bf16(w[n = nt16*16 + (lane&15)][c = c64*64 + ks*32 + (lane>>4)*8 + j][tap])
+__global__ void pack_conv_weight_bf16s_kernel(const float* w, __bf16* out, int N, int C, int taps, int NT16, long total) {
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(it & 7);
+        const int lane = (int)((it >> 3) & 63);
+        long r = it >> 9;
+        const int ks = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % taps);
+        r /= taps;
+        const int nt = (int)(r % NT16);
+        const int c64 = (int)(r / NT16);
+        const int n = nt * 16 + (lane & 15);
+        const int c = c64 * 64 + ks * 32 + (lane >> 4) * 8 + j;
+        out[it] = (__bf16)((n < N && c < C) ? w[((size_t)n * C + c) * taps + tap] : 0.f);
+    }
+}
+
 __global__ void f32_to_bf16_rows_kernel(const float* x, int ldx, __bf16* out, int ldo, int C, long rows) {
     // [rows][ldx] fp32 -> [rows][ldo] bf16: channels [0, C) converted, [C, ldo) zero
     const long total = rows * ldo;
@@ -734,38 +1142,47 @@ __global__ void f32_to_bf16_rows_kernel(const float* x, int ldx, __bf16* out, in
 struct VariantH {
     int wm, wn, tm, tn;
     int ldsw;       // 1: conv_bf16w_kernel (3x3 only; weights and halo through LDS by LDS-DMA)
-    int bm() const { return wm * tm * 32; }
-    int bn() const { return wn * tn * 32; }
+    int mf;         // 1: conv_bf16s_kernel (v_mfma_f32_16x16x32_bf16: tm, tn count 16-wide tiles, weights in layout 1)
+    int bm() const { return wm * tm * (mf ? 16 : 32); }
+    int bn() const { return wn * tn * (mf ? 16 : 32); }
     int nt() const { return wm * wn * 64; }
 };
 
 static const VariantH kVariantsH[] = {
-    {2, 4, 4, 2, 0},   // 0: 256 x 256, 8 waves
-    {2, 2, 4, 2, 0},   // 1: 256 x 128, 4 waves
-    {2, 4, 4, 1, 0},   // 2: 256 x 128, 8 waves
-    {2, 4, 2, 2, 0},   // 3: 128 x 256, 8 waves
-    {2, 2, 2, 2, 0},   // 4: 128 x 128, 4 waves
-    {2, 4, 2, 1, 0},   // 5: 128 x 128, 8 waves
-    {2, 2, 2, 1, 0},   // 6: 128 x  64, 4 waves
-    {2, 2, 1, 1, 0},   // 7:  64 x  64, 4 waves
+    {2, 4, 4, 2, 0, 0},   // 0: 256 x 256, 8 waves
+    {2, 2, 4, 2, 0, 0},   // 1: 256 x 128, 4 waves
+    {2, 4, 4, 1, 0, 0},   // 2: 256 x 128, 8 waves
+    {2, 4, 2, 2, 0, 0},   // 3: 128 x 256, 8 waves
+    {2, 2, 2, 2, 0, 0},   // 4: 128 x 128, 4 waves
+    {2, 4, 2, 1, 0, 0},   // 5: 128 x 128, 8 waves
+    {2, 2, 2, 1, 0, 0},   // 6: 128 x  64, 4 waves
+    {2, 2, 1, 1, 0, 0},   // 7:  64 x  64, 4 waves
     // one pixel row of waves: every wave owns its own n tile(s), so no weight fragment is fetched twice by a block
-    {1, 8, 8, 1, 0},   // 8: 256 x 256, 8 waves, wave tile 256 px x 32 ch
-    {1, 4, 8, 1, 0},   // 9: 256 x 128, 4 waves
-    {1, 8, 4, 1, 0},   // 10: 128 x 256, 8 waves
-    {1, 4, 4, 2, 0},   // 11: 128 x 256, 4 waves, wave tile 128 px x 64 ch
+    {1, 8, 8, 1, 0, 0},   // 8: 256 x 256, 8 waves, wave tile 256 px x 32 ch
+    {1, 4, 8, 1, 0, 0},   // 9: 256 x 128, 4 waves
+    {1, 8, 4, 1, 0, 0},   // 10: 128 x 256, 8 waves
+    {1, 4, 4, 2, 0, 0},   // 11: 128 x 256, 4 waves, wave tile 128 px x 64 ch
     // both operands through LDS (LDS-DMA), 3x3 only
-    {2, 4, 4, 2, 1},   // 12: 256 x 256, 8 waves
-    {2, 4, 2, 2, 1},   // 13: 128 x 256, 8 waves
+    {2, 4, 4, 2, 1, 0},   // 12: 256 x 256, 8 waves
+    {2, 4, 2, 2, 1, 0},   // 13: 128 x 256, 8 waves
+    // v_mfma_f32_16x16x32_bf16 forms (tm, tn in 16-wide tiles)
+    {1, 4, 8, 4, 0, 1},   // 14: 128 x 256, 4 waves, wave tile 128 px x 64 ch
+    {1, 4, 8, 2, 0, 1},   // 15: 128 x 128, 4 waves, wave tile 128 px x 32 ch
+    {2, 2, 4, 4, 0, 1},   // 16: 128 x 128, 4 waves, wave tile  64 px x 64 ch
+    {1, 8, 8, 2, 0, 1},   // 17: 128 x 256, 8 waves
+    {2, 4, 8, 2, 0, 1},   // 18: 256 x 128, 8 waves
+    {2, 2, 4, 2, 0, 1},   // 19: 128 x  64, 4 waves
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
 static size_t lds_bytes_h(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 128 : 256); }
 static size_t lds_bytes_w(const VariantH& V, int hp) {
-    return (size_t)2 * ((hp * 8 + 63) / 64) * 1024 + (size_t)2 * 4 * (V.bn() / 32) * 1024;
+    return (size_t)2 * ((hp * 8 + 63) / 64) * 1024 + (size_t)2 * 4 * (V.bn() / 32) * 1024 + (size_t)V.nt() / 64 * 1024;
 }
 
 static int nbi_of(const VariantH& V, int taps) {
-    return taps == 9 ? (((V.bm() * 25 + 2 * V.nt() - 1) / (2 * V.nt()) + 2) / 3) : ((V.bm() * 16 / V.nt() + 7) / 8);
+    const int ksteps = V.mf ? 4 : 8;
+    return taps == 9 ? (((V.bm() * 25 + 2 * V.nt() - 1) / (2 * V.nt()) + 2) / 3) : ((V.bm() * 16 / V.nt() + ksteps - 1) / ksteps);
 }
 
 static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, TilePlan* best) {
@@ -774,7 +1191,7 @@ static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, Tile
     bool found = false;
     const int pad = taps == 9 ? 1 : 0;
     const int spr = taps == 9 ? 8 : 16;
-    const int maxhi = nbi_of(V, taps) * (taps == 9 ? 3 : 8);
+    const int maxhi = nbi_of(V, taps) * (taps == 9 ? 3 : (V.mf ? 4 : 8));
     for (int twl = 0; twl <= lbm; ++twl) {
         for (int thl = 0; thl + twl <= lbm; ++thl) {
             const int nibl = lbm - twl - thl;
@@ -813,6 +1230,7 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
         if (V.ldsw && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
+        if (V.mf && variant < 0) continue;                        // needs the layout-1 weights: explicit choice only
         TilePlan tp;
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
@@ -853,6 +1271,15 @@ static int launch_w(const ConvArgsH& a, const __bf16* zero16, int grid, size_t l
     return check_launch("nd_conv_bf16_nhwc");
 }
 
+template <int WM, int WN, int TM, int TN, int TAPS>
+static int launch_s(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = conv_bf16s_kernel<WM, WN, TM, TN, TAPS>;
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    return check_launch("nd_conv_bf16_nhwc");
+}
+
 template <int TAPS>
 static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     switch (v) {
@@ -868,6 +1295,12 @@ static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream
         case 9: return launch_h<1, 4, 8, 1, TAPS>(a, grid, lds, s);
         case 10: return launch_h<1, 8, 4, 1, TAPS>(a, grid, lds, s);
         case 11: return launch_h<1, 4, 4, 2, TAPS>(a, grid, lds, s);
+        case 14: return launch_s<1, 4, 8, 4, TAPS>(a, grid, lds, s);
+        case 15: return launch_s<1, 4, 8, 2, TAPS>(a, grid, lds, s);
+        case 16: return launch_s<2, 2, 4, 4, TAPS>(a, grid, lds, s);
+        case 17: return launch_s<1, 8, 8, 2, TAPS>(a, grid, lds, s);
+        case 18: return launch_s<2, 4, 8, 2, TAPS>(a, grid, lds, s);
+        case 19: return launch_s<2, 2, 4, 2, TAPS>(a, grid, lds, s);
     }
     set_error("nd_conv_bf16_nhwc: bad variant %d", v);
     return ND_E_ARG;
@@ -900,12 +1333,24 @@ extern "C" int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize) {
     return (int64_t)(nc64_padded(C) + 1) * nt32 * ksize * ksize * 4 * 512;
 }
 
-extern "C" int nd_repack_conv_weight_bf16(const float* w, void* w_out, int N, int C, int ksize, nd_stream_t stream) {
+extern "C" int nd_conv_bf16_variant_layout(int variant) {
+    if (variant < 0) return 0;
+    if (variant >= kNumVariantsH) return ND_E_ARG;
+    return kVariantsH[variant].mf;
+}
+
+extern "C" int nd_repack_conv_weight_bf16(const float* w, void* w_out, int N, int C, int ksize, int layout,
+                                          nd_stream_t stream) {
     const char* fn = "nd_repack_conv_weight_bf16";
-    ND_REQUIRE(w && w_out && N > 0 && C > 0 && (ksize == 1 || ksize == 3), fn, "bad arguments");
+    ND_REQUIRE(w && w_out && N > 0 && C > 0 && (ksize == 1 || ksize == 3) && (layout == 0 || layout == 1), fn, "bad arguments");
     const long total = (long)nd_conv_bf16_weight_elems(N, C, ksize);
     long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
+    if (layout == 1) {
+        hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                           static_cast<__bf16*>(w_out), N, C, ksize * ksize, 2 * ((N + 31) / 32), total);
+        return check_launch(fn);
+    }
     hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
                        static_cast<__bf16*>(w_out), N, C, ksize * ksize, (N + 31) / 32, total);
     return check_launch(fn);

@@ -308,9 +308,10 @@ class UNetPlan:
         return out
 
     # ------------------------------------------------------------------------------------------------ bf16 convolution
-    def _packed_bf16(self, weight, pad_c_to=None):
+    def _packed_bf16(self, weight, pad_c_to=None, layout=0):
         """fp32 OIHW / [N,C,1] / [N,C] weight -> bf16 MFMA-fragment order, once, on the device (the bf16 half of the
-        weight ingest: the checkpoint stays fp32, the cast happens in the repack)."""
+        weight ingest: the checkpoint stays fp32, the cast happens in the repack).  ``layout``: 0 = fragments of the
+        32x32x16 instruction, 1 = of the 16x16x32 one (nd_conv_bf16_variant_layout of the chosen tile variant)."""
         w = weight.detach().contiguous()
         N, C = w.shape[0], w.shape[1]
         k = w.shape[2] if w.dim() == 4 else 1
@@ -321,7 +322,7 @@ class UNetPlan:
         n = self.lib.nd_conv_bf16_weight_elems(N, C, k)
         assert n > 0
         out = torch.empty(n, dtype=torch.bfloat16, device=self.device)
-        _hip.check(self.lib.nd_repack_conv_weight_bf16(w.data_ptr(), out.data_ptr(), N, C, k, self._stream()),
+        _hip.check(self.lib.nd_repack_conv_weight_bf16(w.data_ptr(), out.data_ptr(), N, C, k, layout, self._stream()),
                    'nd_repack_conv_weight_bf16')
         return out
 
@@ -361,15 +362,17 @@ class UNetPlan:
         if not out.bf16:
             flags |= _hip.CONV_OUT_F32
         C1 = 0 if src2 is None else src2.C
-        wq = self._packed_bf16(weight, pad_c_to)
-        self.keep.append(wq)
-        self.packed_floats += wq.numel() // 2
+        W_SLOT = 6                                   # position of the packed-weight pointer in the argument list
         head = [src.ptr, src.C, src.ld, None if src2 is None else src2.ptr, C1, 0 if src2 is None else src2.ld,
-                wq.data_ptr(), bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
+                None, bias, rowbias, ld_rowbias, None if residual is None else residual.ptr,
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N, ksize, flags]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
-        var = self._pick_bf16(key, fl, head, gn)
+        var = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT)
+        wq = self._packed_bf16(weight, pad_c_to, self.lib.nd_conv_bf16_variant_layout(var))
+        self.keep.append(wq)
+        self.packed_floats += wq.numel() // 2
+        head[W_SLOT] = wq.data_ptr()
         self._emit(self.lib.nd_conv_bf16_nhwc, head + [var] + gn, label, flops=fl, variant=('bf16', var), ksize=ksize,
                    shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
@@ -378,7 +381,7 @@ class UNetPlan:
             self._release(tmp)
         return out
 
-    def _pick_bf16(self, key, flops, head, gn):
+    def _pick_bf16(self, key, flops, head, gn, weight, pad_c_to, w_slot):
         """Tile variant for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with ND_AUTOTUNE=0,
         else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per shape."""
         if not _autotune_enabled() or flops < 2e8:
@@ -389,8 +392,14 @@ class UNetPlan:
         stream = self._stream()
         fn = self.lib.nd_conv_bf16_nhwc
         best, best_ms = -1, None
+        packed = {}                                       # tuning copies of the weights, one per fragment layout
         for v in range(self.lib.nd_conv_bf16_num_variants()):
-            args = head + [v] + gn
+            lay = self.lib.nd_conv_bf16_variant_layout(v)
+            if lay not in packed:
+                packed[lay] = self._packed_bf16(weight, pad_c_to, lay)
+            h = list(head)
+            h[w_slot] = packed[lay].data_ptr()
+            args = h + [v] + gn
             if fn(*args, stream) != 0:
                 continue                                  # this tile shape does not fit the problem
             if not _CLOCK_SETTLED[0]:

@@ -50,7 +50,7 @@ SIGNATURES = {
                                 _i, _i, _i, _i, _f, _i, _i, _vp],
     'nd_conv_bf16_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                           _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
-    'nd_repack_conv_weight_bf16': [_vp, _vp, _i, _i, _i, _vp],
+    'nd_repack_conv_weight_bf16': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_f32_to_bf16_rows': [_vp, _i, _vp, _i, _i, _i64, _vp],
     'nd_attention_bf16_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     'nd_attention_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
@@ -73,6 +73,7 @@ _SPECIAL = {
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
     'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
     'nd_conv_bf16_num_variants': ([], _i),
+    'nd_conv_bf16_variant_layout': ([_i], _i),
     'nd_conv_bf16_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_groupnorm_stats_blocks': ([_i, _i, _i, _i], _i),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),

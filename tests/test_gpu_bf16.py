@@ -60,14 +60,14 @@ def from_nhwc(t, B, H, W, C, ld=None):
     return t.view(B, H, W, ld)[..., :C].permute(0, 3, 1, 2).float().cpu()
 
 
-def pack_bf(w):
+def pack_bf(w, layout=0):
     N, C = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() == 4 else 1
     n = lib().nd_conv_bf16_weight_elems(N, C, k)
     assert n > 0
     out = torch.full((n,), float('nan'), dtype=BF, device=DEV)
     wd = w.contiguous().to(DEV)
-    _hip.check(lib().nd_repack_conv_weight_bf16(wd.data_ptr(), out.data_ptr(), N, C, k, st()))
+    _hip.check(lib().nd_repack_conv_weight_bf16(wd.data_ptr(), out.data_ptr(), N, C, k, layout, st()))
     return out
 
 
@@ -94,6 +94,16 @@ def test_repack_conv_weight_bf16(N, C, k):
                     for tap in (0, taps - 1):
                         assert torch.equal(p[c64, nt, tap, ks, :, j], full[n, c, tap])
     assert not torch.isnan(p).any()
+    # layout 1 (16x16x32 fragments): [c64][n16 tile][tap][ks(2)][lane][8] = w[nt*16 + (lane&15)][c64*64 + ks*32 + (lane>>4)*8 + j][tap]
+    p1 = pack_bf(w, 1).cpu().view(nc + 1, 2 * nt32, taps, 2, 64, 8).float()
+    for c64 in (0, nc - 1, nc):
+        for ks in range(2):
+            for j in (0, 5, 7):
+                c = c64 * 64 + ks * 32 + (lane >> 4) * 8 + j
+                for nt in (0, 2 * nt32 - 1):
+                    n = nt * 16 + (lane & 15)
+                    for tap in (0, taps - 1):
+                        assert torch.equal(p1[c64, nt, tap, ks, :, j], full[n, c, tap])
 
 
 CONV_CASES = [  # B, Cin, Cout, H, W
@@ -113,9 +123,11 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
     w = rnd(Cout, Cin, ksize, ksize, seed=2, scale=0.05)
     b = rnd(Cout, seed=3)
     ref = F.conv2d(q(x).double(), q(w).double(), b.double(), padding=ksize // 2).float()
-    xd, wd, bd = nhwc_bf(x), pack_bf(w if ksize == 3 else w[:, :, 0, 0]), b.to(DEV)
+    xd, bd = nhwc_bf(x), b.to(DEV)
+    wds = [pack_bf(w if ksize == 3 else w[:, :, 0, 0], lay) for lay in (0, 1)]
     ran = 0
     for v in list(range(lib().nd_conv_bf16_num_variants())) + [-1]:
+        wd = wds[lib().nd_conv_bf16_variant_layout(v)]
         for f32out in (False, True):
             out = torch.full((B * H * W * Cout,), float('nan'), dtype=torch.float32 if f32out else BF, device=DEV)
             rc = lib().nd_conv_bf16_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
@@ -204,8 +216,10 @@ def test_conv_bf16_fused_groupnorm(ksize, silu):
                                          cA.data_ptr(), cB.data_ptr(), C, B, C, H * W, 32, 1e-5, st()))
     flags = _hip.CONV_GN_SILU if silu else 0
     ran = 0
+    wds = [wd, pack_bf(w if ksize == 3 else w[:, :, 0, 0], 1)]
     for v in range(lib().nd_conv_bf16_num_variants()):
         out = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        wd = wds[lib().nd_conv_bf16_variant_layout(v)]
         rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
                                      None, 0, out.data_ptr(), N, B, H, W, N, ksize, flags, v, cA.data_ptr(), cB.data_ptr(), C,
                                      st())
@@ -233,8 +247,10 @@ def test_conv_bf16_long_k_full_size_layer():
     xad, xbd, wd, bd = nhwc_bf(xa), nhwc_bf(xb), pack_bf(w), b.to(DEV)
     ref = F.conv2d(torch.cat([q(xa), q(xb)], 1), q(w), b, padding=1)       # fp32 CPU conv on the same bf16 operands
     outs = []
+    wds = [wd, pack_bf(w, 1)]
     for v in range(lib().nd_conv_bf16_num_variants()):
         out = torch.empty(B * H * W * N, dtype=torch.float32, device=DEV)
+        wd = wds[lib().nd_conv_bf16_variant_layout(v)]
         rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
                                      None, 0, out.data_ptr(), N, B, H, W, N, 3, _hip.CONV_OUT_F32, v, None, None, 0, st())
         if rc == 0:

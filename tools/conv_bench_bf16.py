@@ -18,13 +18,18 @@ torch.manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 x = torch.randn(NI * H * W * C, device=dev).to(torch.bfloat16)
 w0 = torch.randn(N, C, ks, ks, device=dev) * 0.02
-w = torch.empty(lib.nd_conv_bf16_weight_elems(N, C, ks), dtype=torch.bfloat16, device=dev)
-assert lib.nd_repack_conv_weight_bf16(w0.data_ptr(), w.data_ptr(), N, C, ks, st) == 0
+ws = []
+for lay in (0, 1):
+    wl = torch.empty(lib.nd_conv_bf16_weight_elems(N, C, ks), dtype=torch.bfloat16, device=dev)
+    assert lib.nd_repack_conv_weight_bf16(w0.data_ptr(), wl.data_ptr(), N, C, ks, lay, st) == 0
+    ws.append(wl)
 b = torch.randn(N, device=dev)
 out = torch.empty(NI * H * W * N, dtype=torch.bfloat16, device=dev)
 fl = 2.0 * NI * H * W * N * ks * ks * C
 warm = False
 for v in variants:
+    w = ws[lib.nd_conv_bf16_variant_layout(v)]
+
     def run():
         return lib.nd_conv_bf16_nhwc(x.data_ptr(), C, C, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0,
                                      out.data_ptr(), N, NI, H, W, N, ks, 0, v, None, None, 0, st)
