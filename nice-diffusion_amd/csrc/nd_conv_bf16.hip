@@ -1329,8 +1329,9 @@ extern "C" int nd_conv_bf16_variant_info(int variant, int* bm, int* bn, int* thr
 extern "C" int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize) {
     if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3)) return ND_E_ARG;
     const int64_t nt32 = (N + 31) / 32;
-    // + 1 chunk of zeros: the fragment stream runs 3 k-steps ahead of the last real one
-    return (int64_t)(nc64_padded(C) + 1) * nt32 * ksize * ksize * 4 * 512;
+    // + 2 chunks of zeros: the fragment stream runs up to 3 fragments ahead of the last real one, and a 16x16x32 1x1 stream
+    // has only 2 fragments per chunk and n tile (a single padding chunk was overrun by one fragment there)
+    return (int64_t)(nc64_padded(C) + 2) * nt32 * ksize * ksize * 4 * 512;
 }
 
 extern "C" int nd_conv_bf16_variant_layout(int variant) {

@@ -78,14 +78,14 @@ def test_repack_conv_weight_bf16(N, C, k):
     taps = k * k
     nt32 = (N + 31) // 32
     nc = ((C + 63) // 64 + 1) & ~1
-    assert packed.numel() == (nc + 1) * nt32 * taps * 4 * 512
-    p = packed.view(nc + 1, nt32, taps, 4, 64, 8).float()
+    assert packed.numel() == (nc + 2) * nt32 * taps * 4 * 512
+    p = packed.view(nc + 2, nt32, taps, 4, 64, 8).float()
     wq = q(w).reshape(N, C, taps)
-    full = torch.zeros(nt32 * 32, (nc + 1) * 64, taps)
+    full = torch.zeros(nt32 * 32, (nc + 2) * 64, taps)
     full[:N, :C] = wq
     # element [c64][nt][tap][ks][lane][j] = w[nt*32 + (lane&31)][c64*64 + ks*16 + (lane>>5)*8 + j][tap]
     lane = torch.arange(64)
-    for c64 in (0, nc - 1, nc):
+    for c64 in (0, nc - 1, nc, nc + 1):
         for ks in range(4):
             for j in (0, 3, 7):
                 c = c64 * 64 + ks * 16 + (lane >> 5) * 8 + j
@@ -95,8 +95,8 @@ def test_repack_conv_weight_bf16(N, C, k):
                         assert torch.equal(p[c64, nt, tap, ks, :, j], full[n, c, tap])
     assert not torch.isnan(p).any()
     # layout 1 (16x16x32 fragments): [c64][n16 tile][tap][ks(2)][lane][8] = w[nt*16 + (lane&15)][c64*64 + ks*32 + (lane>>4)*8 + j][tap]
-    p1 = pack_bf(w, 1).cpu().view(nc + 1, 2 * nt32, taps, 2, 64, 8).float()
-    for c64 in (0, nc - 1, nc):
+    p1 = pack_bf(w, 1).cpu().view(nc + 2, 2 * nt32, taps, 2, 64, 8).float()
+    for c64 in (0, nc - 1, nc, nc + 1):
         for ks in range(2):
             for j in (0, 5, 7):
                 c = c64 * 64 + ks * 32 + (lane >> 4) * 8 + j

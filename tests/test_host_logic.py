@@ -236,7 +236,7 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and 'multiples of 8' in _hip.last_error()
     rc = lib.nd_attention_bf16_nhwc(16, 96, 16, 32, 1, 64, 1, 12, 0, 32, 64, 12, 1.0, None)
     assert rc == -1 and 'multiple of 8' in _hip.last_error()
-    assert lib.nd_conv_bf16_weight_elems(96, 70, 3) == (2 + 1) * 3 * 9 * 4 * 512      # 70 ch -> 2 chunks of 64 (+1 zero chunk)
+    assert lib.nd_conv_bf16_weight_elems(96, 70, 3) == (2 + 2) * 3 * 9 * 4 * 512      # 70 ch -> 2 chunks of 64 (+2 zero chunks)
     assert 1 <= lib.nd_groupnorm_stats_blocks(64, 4096, 192, _hip.DT_F32) <= 32 and lib.nd_groupnorm_stats_blocks(2, 64, 64, _hip.DT_BF16) >= 1
 
 
