@@ -470,3 +470,38 @@ def test_config4_workload_bf16_ddpm_cfg_128():
     d.use_graph = False
     c = d.denoise(x=xb, kwargs={'y': yb.to(DEV)}, batch_size=B, steps_to_do=3, progress=False)
     assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_sample_cli_in_bf16(tmp_path, monkeypatch):
+    """scripts/sample.py with ND_COMPUTE_DTYPE=bf16 (the reference's CLI has no precision flag for sampling): same files,
+    images within two grey levels of the fp32 run."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'nice-diffusion_amd', 'scripts'))
+    import sample
+    cfg = dict(TINY_CFGS['adagn_updown'])
+    sd = UO.synth_state_dict(cfg, seed=11)
+    ckpt = str(tmp_path / 'tiny_model.pt')
+    torch.save(sd, ckpt)
+    outs = {}
+    for mode in ('fp32', 'bf16'):
+        out_dir = str(tmp_path / mode) + '/'
+        os.makedirs(out_dir)
+        monkeypatch.setenv('ND_COMPUTE_DTYPE', mode)
+        argv = ['--model_path', ckpt, '--custom', '--batch_size', '2', '--num_samples', '1', '--resolution', '16',
+                '--model_channels', '32', '--channel_mult', '1/2', '--num_res_blocks', '1', '--attention_resolutions', '8',
+                '--num_classes', '10', '--num_head_channels', '32', '--split_qkv_first', '--resblock_updown', '--use_adaptive_gn',
+                '--rescaled_num_steps', '5', '--beta_schedule', 'cosine', '--sampling_var_type', 'learned_interpolation',
+                '--use_ddim', '--ddim_eta', '0.0', '--seed', '0', '--labels', '3', '--save_path', out_dir]
+        sample.main(argv)
+        assert sorted(os.listdir(out_dir)) == ['3_sample0.jpg', '3_sample1.jpg']
+        # the same samples through the library, for a numeric comparison (JPEG bytes are lossy)
+        m = build(cfg, seed=11, dtype=mode)
+        d = Diffusion(m, 1000, 5, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0,
+                      device=torch.device(DEV))
+        torch.manual_seed(0)
+        xT = torch.randn(2, 3, 16, 16)
+        outs[mode] = sample.saved_bytes(d.denoise(x=xT, kwargs={'y': torch.tensor([3, 3]).to(DEV)}, batch_size=2,
+                                                  progress=False), 3).astype(int)
+    monkeypatch.delenv('ND_COMPUTE_DTYPE')
+    assert np.abs(outs['fp32'] - outs['bf16']).max() <= 2
