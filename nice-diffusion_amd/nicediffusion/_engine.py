@@ -477,6 +477,11 @@ class UNetPlan:
                 # kept (and tested) as an explicit variant but is not a tuning candidate unless asked for
                 if not dma_ok and self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16g_kernel':
                     continue
+                # the persistent form (one block per CU walking several tiles, next tile's first chunk prefetched) gives the
+                # same bits but measures 25-30 % slower: explicit variant, not a tuning candidate
+                if os.environ.get('ND_WINO_PERSISTENT', '0') != '1' and \
+                        self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel':
+                    continue
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms

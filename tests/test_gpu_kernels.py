@@ -131,8 +131,11 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
     xd, wd, bd = nhwc(x), pack_wino(w), b.to(DEV)
     for v in range(lib().nd_conv_winograd_num_variants()):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
-        _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
-                                                  None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st()))
+        rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                            None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st())
+        if rc != 0:      # only the persistent form may decline a shape (odd number of 32-channel chunks)
+            assert lib().nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
+            continue
         got = from_nhwc(out, B, H, W, Cout)
         assert torch.isfinite(got).all(), v
         assert (got - ref).abs().max().item() < 2e-4, (v, (got - ref).abs().max().item())
@@ -140,6 +143,36 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
     rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, None, 0,
                                         out.data_ptr(), Cout, B, H - 1, W, Cout, 0, 0, None, None, 0, st())
     assert rc == -1 and 'even' in _hip.last_error()
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(8, 64, 192, 64, 64), (64, 128, 96, 8, 8), (3, 192, 200, 32, 32), (1, 64, 96, 16, 16)])
+def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W):
+    """conv_wino16p_kernel (one block per CU walking several tiles, the next tile's first chunk fetched during the current
+    tile's last one) gives the SAME BITS as conv_wino16_kernel: several tiles per block, N tails, two-source input,
+    per-image bias and residual included."""
+    names = [lib().nd_conv_winograd_variant_name(v) for v in range(lib().nd_conv_winograd_num_variants())]
+    v1, vp = names.index(b'nd::conv_wino16_kernel<1>'), names.index(b'nd::conv_wino16p_kernel')
+    C0 = Cin // 2
+    xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, Cin - C0, H, W, seed=2)
+    w, b = rnd(Cout, Cin, 3, 3, seed=3, scale=0.05), rnd(Cout, seed=4)
+    rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
+    ref = F.conv2d(torch.cat([xa, xb], 1), w, b, padding=1) + rb[:, :, None, None] + res
+    wd, xad, xbd, bd, rbd, resd = pack_wino(w), nhwc(xa), nhwc(xb), b.to(DEV), rb.to(DEV), nhwc(res)
+    outs = []
+    for v in (v1, vp):
+        out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), Cin - C0, Cin - C0, wd.data_ptr(),
+                                                  bd.data_ptr(), rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(),
+                                                  Cout, B, H, W, Cout, 0, v, None, None, 0, st()))
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert (from_nhwc(outs[1], B, H, W, Cout) - ref).abs().max().item() < 2e-4
+    # and twice in a row (the loop state must not leak between launches)
+    out2 = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), Cin - C0, Cin - C0, wd.data_ptr(),
+                                              bd.data_ptr(), rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out2.data_ptr(),
+                                              Cout, B, H, W, Cout, 0, vp, None, None, 0, st()))
+    assert torch.equal(out2, outs[1])
 
 
 def test_conv3x3_winograd_fused_options():
@@ -158,10 +191,13 @@ def test_conv3x3_winograd_fused_options():
     ref3 = F.silu(F.conv2d(x, w2, b, padding=1))
     for v in range(lib().nd_conv_winograd_num_variants()):
         out = torch.empty(B * H * W * Cout, device=DEV)
-        _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
-                                                  rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
-                                                  Cout, 0, v, None, None, 0, st()))
-        assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
+        rc = lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
+                                            rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
+                                            Cout, 0, v, None, None, 0, st())
+        if rc != 0:      # 96 input channels = 3 chunks: the persistent form declines (it is covered by its own test)
+            assert lib().nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
+        else:
+            assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
         out = torch.empty(B * 4 * H * W * Cout, device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
                                                   rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout,
