@@ -1231,6 +1231,7 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
         const VariantH& V = kVariantsH[v];
         if (V.ldsw && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
         if (V.mf && variant < 0) continue;                        // needs the layout-1 weights: explicit choice only
+        if (V.mf && V.tm * V.tn >= 32) continue;                  // 128 px x 64 ch wave tile on 16x16 MFMAs: 154 registers spill (10x slower); kept only as an index
         TilePlan tp;
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
