@@ -1089,6 +1089,194 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// GEMM-shaped 1x1 form (flat pixel list): out[M][N] = x[M][K] . w[N][K]^T with K of a few hundred.  In the conv-shaped
+// 1x1 path above a block lives for 2-8 chunks, each chunk's rows are fetched only one chunk ahead through registers, and
+// the waves sit parked 60-70 % of the time (PMC: MFMA pipe busy 0.12-0.18).  Here BOTH operands go through a ring of THREE
+// LDS stages filled by LDS-DMA (a 64-channel chunk per stage: 256 pixel rows x 128 bytes, swizzle on the source address,
+// + the chunk's 4 k-steps x 4 n-tile weight fragments), so a chunk has two whole chunks of compute (~2000 cycles) to arrive;
+// per stage every wave issues exactly 4 + 2 DMAs, which makes the one counted wait per chunk (vmcnt(6): everything but the
+// youngest stage has landed) uniform.  8 waves = 4 (pixels) x 2 (channels), wave tile 64 px x 64 ch, block 256 px x 128 ch.
+template <int DUMMY>
+__global__ void __launch_bounds__(512, 2)
+    gemm_bf16_kernel(const ConvArgsH p, const __bf16* zero16) {
+    constexpr int BM = 256, BN = 128, TM = 2, TN = 2;
+    constexpr int A_W = BM * 32;                      // words of the A part of a stage (256 rows x 128 bytes)
+    constexpr int STAGE_W = A_W + 16 * 256;           // + 16 weight fragments of 1 KiB
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 stages
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int M = p.W;                                 // flat pixel list
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = p.NC64;
+
+    auto swz = [](int row) -> int { return (row >> 1) & 7; };
+
+    // ---- A DMA descriptors: piece u = j * 8 + wave (j = 0..3) = rows 8u .. 8u+7; lane -> row 8u + lane/8, physical slot lane%8
+    int arow[4], asl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j * 8 + wave) * 8 + (lane >> 3);
+        arow[j] = (m0 + row < M) ? (m0 + row) : -1;
+        asl[j] = ((lane & 7) ^ swz(row)) << 3;       // first channel (within the chunk) of the logical slot this lane fills
+    }
+    // ---- weight DMA descriptors: fragment f = j * 8 + wave (j = 0, 1) = (k-step f / 4, n tile f % 4)
+    const __bf16* wsrc[2];
+    int wdst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = j * 8 + wave;
+        const int ks = f >> 2, nl = f & 3;
+        int ntile = nblk * 4 + nl;
+        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
+        wsrc[j] = p.w + ((size_t)ntile * 4 + ks) * 512 + lane * 8;
+        wdst[j] = A_W + f * 256;
+    }
+    const size_t c64_stride = (size_t)p.NT32 * 4 * 512;
+    auto issue_stage = [&](int ch, int buf) {
+        float* st = smem + buf * STAGE_W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = ch * 64 + asl[j];
+            const int g = arow[j];
+            const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
+                                           : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
+            src = (g >= 0 && c < Ctot) ? src : zero16;
+            ND_GLDS16H(src, st + (j * 8 + wave) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ND_GLDS16H(wsrc[j] + (size_t)ch * c64_stride, st + wdst[j]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // this lane's two A rows (word offsets inside a stage; the slot is added per k-step) and its two weight fragments
+    int aoff[TM], asw[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = (wm * TM + mi) * 32 + l31;
+        aoff[mi] = row * 32;
+        asw[mi] = swz(row);
+    }
+    const int boff = A_W + ((wn * TN) * 64 + lane) * 4;
+
+    issue_stage(0, 0);
+    if (nchunks > 1) {
+        issue_stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;                                       // stage of chunk ch = ch % 3
+    for (int ch = 0; ch < nchunks; ++ch) {
+        int nb2 = buf + 2;
+        if (nb2 >= 3) nb2 -= 3;
+        if (ch + 2 < nchunks) issue_stage(ch + 2, nb2);            // into the stage chunk ch-1 was read from (barrier passed)
+        const float* st = smem + buf * STAGE_W;
+        f32x4 a_fr[2][TM], b_fr[2][TN];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) b_fr[0][ni] = *reinterpret_cast<const f32x4*>(st + boff + ni * 256);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) a_fr[0][mi] = *reinterpret_cast<const f32x4*>(st + aoff[mi] + ((lh ^ asw[mi]) << 2));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks < 3) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    b_fr[nxt][ni] = *reinterpret_cast<const f32x4*>(st + boff + ((ks + 1) * 4 + ni) * 256);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    a_fr[nxt][mi] = *reinterpret_cast<const f32x4*>(st + aoff[mi] + (((((ks + 1) << 1) | lh) ^ asw[mi]) << 2));
+            }
+            ND_PRIO(1);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b_fr[cur][ni]), as_bf16x8(a_fr[cur][mi]),
+                                                                          acc[mi][ni], 0, 0, 0);
+            ND_PRIO(0);
+        }
+        // publish the NEXT chunk: all but this wave's youngest stage (6 DMAs, issued above) has landed; the last two
+        // iterations issue nothing, so everything outstanding is awaited
+        if (ch + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = (buf == 2) ? 0 : buf + 1;
+    }
+
+    // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + l31;
+        if (m < M) {
+            const size_t opix = (size_t)m;
+            const __bf16* rr = p.res ? p.res + opix * p.ldr : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                    if (n + 3 < p.N && vec_ok) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rr) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        if (p.out_f32) {
+                            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + opix * p.ldo + n) = v;
+                        } else {
+                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = acc[mi][ni][4 * g4 + e];
+                                if (p.bias) v += p.bias[n + e];
+                                if (rr) v += (float)rr[n + e];
+                                if (p.silu_out) v = fast_silu(v);
+                                if (p.out_f32) static_cast<float*>(p.out)[opix * p.ldo + n + e] = v;
+                                else static_cast<__bf16*>(p.out)[opix * p.ldo + n + e] = (__bf16)v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 OIHW [N][C][k][k] (also Conv1d [N][C][1], Linear [N][C]) -> bf16 fragment order
 //   out[((((c64*NT32 + ntile)*taps + tap)*4 + ks)*64 + lane)*8 + j] = bf16(w[n = ntile*32 + (lane&31)][c = c64*64 + ks*16 + (lane>>5)*8 + j][tap])
 // zero for n >= N, c >= C and for the padding chunks.
@@ -1172,6 +1360,8 @@ static const VariantH kVariantsH[] = {
     {1, 8, 8, 2, 0, 1},   // 17: 128 x 256, 8 waves
     {2, 4, 8, 2, 0, 1},   // 18: 256 x 128, 8 waves
     {2, 2, 4, 2, 0, 1},   // 19: 128 x  64, 4 waves
+    // GEMM-shaped 1x1 (flat pixel lists only): three LDS stages filled by LDS-DMA; coded as ldsw = 2
+    {4, 2, 2, 2, 2, 0},   // 20: 256 x 128, 8 waves
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
@@ -1197,7 +1387,9 @@ static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, Tile
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2 * pad) * (TW + 2 * pad);
-            if (V.ldsw) {
+            if (V.ldsw == 2) {
+                if (thl != 0 || nibl != 0) continue;                       // a flat run of 256 pixels
+            } else if (V.ldsw) {
                 if ((hp * 8 + 63) / 64 > 9 * (nt / 64)) continue;        // one 1 KiB halo piece per wave and tap
                 if (lds_bytes_w(V, hp) > 160 * 1024) continue;
             } else {
@@ -1229,14 +1421,15 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
     for (int v = 0; v < kNumVariantsH; ++v) {
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
-        if (V.ldsw && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
+        if (V.ldsw == 1 && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
+        if (V.ldsw == 2 && (taps != 1 || variant < 0 || pNI != 1 || pH != 1)) continue;      // flat 1x1 only, explicit choice only
         if (V.mf && variant < 0) continue;                        // needs the layout-1 weights: explicit choice only
         if (V.mf && V.tm * V.tn >= 32) continue;                  // 128 px x 64 ch wave tile on 16x16 MFMAs: 154 registers spill (10x slower); kept only as an index
         TilePlan tp;
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
         const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp);
+        const size_t lds = V.ldsw == 2 ? (size_t)3 * 48 * 1024 : (V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp));
         int per_cu = (int)(160 * 1024 / lds);
         const int by_waves = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;      // two waves per SIMD
         if (per_cu > by_waves) per_cu = by_waves;
@@ -1443,6 +1636,15 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
     }
     const int grid = a.mt * a.nt;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (V.ldsw == 2) {
+        ND_REQUIRE(gnA == nullptr && rowbias == nullptr, fn, "the GEMM form takes plain 1x1 convolutions only");
+        const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;
+        auto kern = gemm_bf16_kernel<0>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, fn)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)3 * 48 * 1024, s, a, zero16);
+        return check_launch(fn);
+    }
     if (V.ldsw) {
         // 16 bytes of zeros for padded halo units: the tail of the packed weights' trailing zero chunk
         const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;
