@@ -147,8 +147,9 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
             lib.nd_conv_winograd_variant_name(var).decode(), bm.value, bn.value, nt.value)
     elif kind == 'bf16':
         lib.nd_conv_bf16_variant_info(max(var, 0), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
-        kname = 'nd::conv_bf16_kernel<{}x{} tile, {} threads, {} taps> (v_mfma_f32_32x32x16_bf16)'.format(
-            bm.value, bn.value, nt.value, ksize * ksize)
+        kname = '{}<{}x{} tile, {} threads, {} taps> ({})'.format(
+            lib.nd_conv_bf16_variant_name(max(var, 0)).decode(), bm.value, bn.value, nt.value, ksize * ksize,
+            'v_mfma_f32_16x16x32_bf16' if lib.nd_conv_bf16_variant_layout(max(var, 0)) else 'v_mfma_f32_32x32x16_bf16')
     else:
         lib.nd_conv_variant_info(var, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         kname = 'nd::conv_mfma_kernel<{}x{} tile, {} threads, {} taps>'.format(bm.value, bn.value, nt.value, ksize * ksize)

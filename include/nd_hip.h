@@ -144,6 +144,9 @@ int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize);
 /* layout 0: fragments of v_mfma_f32_32x32x16_bf16; layout 1: of v_mfma_f32_16x16x32_bf16 -- a variant takes the layout
  * nd_conv_bf16_variant_layout(variant) names (0 for variant < 0); both have nd_conv_bf16_weight_elems elements. */
 int nd_conv_bf16_variant_layout(int variant);
+/* Kernel behind a tile variant ("nd::conv_bf16_kernel", "nd::conv_bf16s_kernel", "nd::conv_bf16w_kernel",
+ * "nd::gemm_bf16_kernel"); "" for an unknown variant. */
+const char* nd_conv_bf16_variant_name(int variant);
 int nd_repack_conv_weight_bf16(const float* w_oihw, void* w_out, int N, int C, int ksize, int layout, nd_stream_t stream);
 int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, int C, int64_t rows, nd_stream_t stream);
 int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,

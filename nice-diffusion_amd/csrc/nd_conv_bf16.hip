@@ -1528,6 +1528,13 @@ extern "C" int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize) {
     return (int64_t)(nc64_padded(C) + 2) * nt32 * ksize * ksize * 4 * 512;
 }
 
+extern "C" const char* nd_conv_bf16_variant_name(int variant) {
+    if (variant < 0 || variant >= kNumVariantsH) return "";
+    const VariantH& v = kVariantsH[variant];
+    return v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
+                                                                                               : "nd::conv_bf16_kernel";
+}
+
 extern "C" int nd_conv_bf16_variant_layout(int variant) {
     if (variant < 0) return 0;
     if (variant >= kNumVariantsH) return ND_E_ARG;

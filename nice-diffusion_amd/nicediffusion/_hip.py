@@ -74,6 +74,7 @@ _SPECIAL = {
     'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
     'nd_conv_bf16_num_variants': ([], _i),
     'nd_conv_bf16_variant_layout': ([_i], _i),
+    'nd_conv_bf16_variant_name': ([_i], ctypes.c_char_p),
     'nd_conv_bf16_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_groupnorm_stats_blocks': ([_i, _i, _i, _i], _i),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
