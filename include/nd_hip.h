@@ -144,6 +144,17 @@ int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize);
 /* layout 0: fragments of v_mfma_f32_32x32x16_bf16; layout 1: of v_mfma_f32_16x16x32_bf16 -- a variant takes the layout
  * nd_conv_bf16_variant_layout(variant) names (0 for variant < 0); both have nd_conv_bf16_weight_elems elements. */
 int nd_conv_bf16_variant_layout(int variant);
+/* 3x3 bf16 convolution that also leaves the statistics of its (bf16-rounded) output behind for the next GroupNorm
+ * (model.py:190,201-207 read the tensor this conv writes): chstats rows [NI][rows][sum | sum of squares][N] in fp32, one
+ * row per (pixel tile of the image, wave row), every row written by every launch (no zeroing, no atomics, fixed order).
+ * rows = nd_conv_bf16_stats_rows(NI, H, W, N, variant) (0: this variant / shape cannot: LDS-DMA and 16x16x32 forms,
+ * several images per block, N % 4 != 0).  nd_groupnorm_stats_from_partials folds the rows.  The variant must be named. */
+int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant);
+int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                               const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                               const void* residual, int ldr, void* out, int ldo,
+                               int NI, int H, int W, int N, int flags, int variant,
+                               const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream);
 /* Kernel behind a tile variant ("nd::conv_bf16_kernel", "nd::conv_bf16s_kernel", "nd::conv_bf16w_kernel",
  * "nd::gemm_bf16_kernel"); "" for an unknown variant. */
 const char* nd_conv_bf16_variant_name(int variant);

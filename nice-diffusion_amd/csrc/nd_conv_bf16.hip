@@ -50,7 +50,26 @@ struct ConvArgsH {
     const float* gnA;
     const float* gnB;
     int ld_gn, gn_silu, gn_hw;
+    // partial GroupNorm statistics of the OUTPUT (STATS instantiations): rows [img][cs_rows][sum | sum of squares][N],
+    // one row per (pixel tile of the image, wave row), every row written by every launch
+    float* chstats;
+    int cs_rows;
 };
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 32 lanes that share lane >> 5, in a fixed order, result in every lane: xor 1, xor 2 (quad permutes), mirror
+// within 8, mirror within 16 (DPP, folded into the adds), then lane ^ 16 by ds_swizzle (no LDS memory involved)
+__device__ __forceinline__ float sum_over_32_lanes(float x) {
+    x += dpp_move<0xB1>(x);
+    x += dpp_move<0x4E>(x);
+    x += dpp_move<0x141>(x);
+    x += dpp_move<0x140>(x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+    return x;
+}
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     union { f32x4 f; bf16x8 h; } u;
@@ -58,7 +77,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     return u.h;
 }
 
-template <int WM, int WN, int TM, int TN, int TAPS>
+template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
     conv_bf16_kernel(const ConvArgsH p) {
     constexpr int NT = WM * WN * 64;
@@ -378,6 +397,74 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #endif
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
+    if constexpr (STATS) {
+        // the same epilogue, channel groups outermost, which also leaves per-channel sums / sums of squares of the bf16
+        // values it stores (the next GroupNorm's statistics) in row (pixel tile, wave row) of p.chstats.  Host-checked:
+        // one image per block, N % 4 == 0, vector-friendly strides, bf16 output.
+        int opix[TM], rpix[TM];
+        bool ok[TM];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = (wm * TM + mi) * 32 + l31;
+            const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+            const int ox = ox0 + (m & (TW - 1));
+            ok[mi] = oy < p.H && ox < p.W;
+            opix[mi] = (img0 * p.H + oy) * p.W + ox;
+            rpix[mi] = p.res_up ? (img0 * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1) : opix[mi];
+        }
+        const float* rb = p.rowbias ? p.rowbias + (size_t)img0 * p.ld_rowbias : nullptr;
+        float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                const bool nok = n + 3 < p.N;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rbv = {0.f, 0.f, 0.f, 0.f};      // added in the plain epilogue's order
+                if (nok) {
+                    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (rb) rbv = *reinterpret_cast<const f32x4*>(rb + n);
+                }
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    if (nok && ok[mi]) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += bv;
+                        if (rb) v += rbv;
+                        if (p.res) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + (size_t)rpix[mi] * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + (size_t)opix[mi] * p.ldo + n) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r = (float)o[e];
+                            s1[e] += r;
+                            s2[e] += r * r;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] = sum_over_32_lanes(s1[e]);
+                    s2[e] = sum_over_32_lanes(s2[e]);
+                }
+                if (nok && l31 == 0) {
+                    *reinterpret_cast<f32x4*>(cs + n) = s1;
+                    *reinterpret_cast<f32x4*>(cs + p.N + n) = s2;
+                }
+            }
+        }
+        return;
+    }
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -1447,9 +1534,9 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
     return best_v;
 }
 
-template <int WM, int WN, int TM, int TN, int TAPS>
+template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
 static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS>;
+    auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS, STATS>;
     static bool attr_set[kMaxDevices] = {};
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
@@ -1497,6 +1584,26 @@ static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream
         case 19: return launch_s<2, 2, 4, 2, TAPS>(a, grid, lds, s);
     }
     set_error("nd_conv_bf16_nhwc: bad variant %d", v);
+    return ND_E_ARG;
+}
+
+// 3x3 launches that also leave the output's per-channel partial sums behind (ConvArgsH::chstats)
+static int dispatch_h_stats(int v, const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
+    switch (v) {
+        case 0: return launch_h<2, 4, 4, 2, 9, true>(a, grid, lds, s);
+        case 1: return launch_h<2, 2, 4, 2, 9, true>(a, grid, lds, s);
+        case 2: return launch_h<2, 4, 4, 1, 9, true>(a, grid, lds, s);
+        case 3: return launch_h<2, 4, 2, 2, 9, true>(a, grid, lds, s);
+        case 4: return launch_h<2, 2, 2, 2, 9, true>(a, grid, lds, s);
+        case 5: return launch_h<2, 4, 2, 1, 9, true>(a, grid, lds, s);
+        case 6: return launch_h<2, 2, 2, 1, 9, true>(a, grid, lds, s);
+        case 7: return launch_h<2, 2, 1, 1, 9, true>(a, grid, lds, s);
+        case 8: return launch_h<1, 8, 8, 1, 9, true>(a, grid, lds, s);
+        case 9: return launch_h<1, 4, 8, 1, 9, true>(a, grid, lds, s);
+        case 10: return launch_h<1, 8, 4, 1, 9, true>(a, grid, lds, s);
+        case 11: return launch_h<1, 4, 4, 2, 9, true>(a, grid, lds, s);
+    }
+    set_error("nd_conv_bf16_stats_nhwc: variant %d cannot leave statistics behind", v);
     return ND_E_ARG;
 }
 
@@ -1568,12 +1675,14 @@ extern "C" int nd_f32_to_bf16_rows(const float* x, int ldx, void* out, int ldo, 
     return check_launch(fn);
 }
 
-extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                                 const void* w, const float* bias, const float* rowbias, int ld_rowbias,
-                                 const void* residual, int ldr, void* out, int ldo,
-                                 int NI, int H, int W, int N, int ksize, int flags, int variant,
-                                 const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
-    const char* fn = "nd_conv_bf16_nhwc";
+// chstats == nullptr: the plain convolution.  Otherwise (3x3, conv_bf16_kernel variants, one image per block) the launch
+// also writes the output's partial per-channel statistics; stats_rows_only: no launch, return the rows per image.
+static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                          const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                          const void* residual, int ldr, void* out, int ldo,
+                          int NI, int H, int W, int N, int ksize, int flags, int variant,
+                          const float* gnA, const float* gnB, int ld_gn, float* chstats, bool stats_rows_only,
+                          nd_stream_t stream) {
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -1605,8 +1714,18 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
     const int v = select_variant_h(variant, taps, pNI, pH, pW, N, &tp);
     if (v < 0) return fail_arg(fn, "no tile variant fits this shape");
     const VariantH& V = kVariantsH[v];
+    const bool stats = chstats != nullptr || stats_rows_only;
+    if (stats) {
+        ND_REQUIRE(taps == 9 && !V.ldsw && !V.mf, fn, "statistics: 3x3 convolutions by the conv_bf16_kernel variants only");
+        ND_REQUIRE(tp.nibl == 0, fn, "statistics need one image per block (H*W >= pixel tile)");
+        ND_REQUIRE((N & 3) == 0 && (ldo & 3) == 0 && (!residual || (ldr & 3) == 0) && (!rowbias || (ld_rowbias & 3) == 0) &&
+                   !(flags & ND_CONV_OUT_F32), fn, "statistics: N and the strides must be multiples of 4, bf16 output");
+        if (stats_rows_only) return tp.tiles_x * tp.tiles_y * V.wm;
+    }
 
     ConvArgsH a;
+    a.chstats = chstats;
+    a.cs_rows = tp.tiles_x * tp.tiles_y * V.wm;
     a.x0 = static_cast<const __bf16*>(x0);
     a.x1 = (C1 > 0) ? static_cast<const __bf16*>(x1) : a.x0;
     a.w = static_cast<const __bf16*>(w);
@@ -1663,5 +1782,36 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
         return fail_arg(fn, "bad variant");
     }
     const size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
+    if (chstats) return dispatch_h_stats(v, a, grid, lds, s);
     return (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
+}
+
+extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                 const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                 const void* residual, int ldr, void* out, int ldo,
+                                 int NI, int H, int W, int N, int ksize, int flags, int variant,
+                                 const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
+    return conv_bf16_impl("nd_conv_bf16_nhwc", x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
+                          NI, H, W, N, ksize, flags, variant, gnA, gnB, ld_gn, nullptr, false, stream);
+}
+
+extern "C" int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant) {
+    const char* fn = "nd_conv_bf16_stats_rows";
+    ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && variant >= 0 && variant < kNumVariantsH, fn, "bad arguments");
+    const VariantH& V = kVariantsH[variant];
+    if (V.ldsw || V.mf || (N & 3)) return 0;
+    TilePlan tp{};
+    if (select_variant_h(variant, 9, NI, H, W, N, &tp) < 0 || tp.nibl != 0) return 0;
+    return tp.tiles_x * tp.tiles_y * V.wm;
+}
+
+extern "C" int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                          const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                          const void* residual, int ldr, void* out, int ldo,
+                                          int NI, int H, int W, int N, int flags, int variant,
+                                          const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream) {
+    const char* fn = "nd_conv3x3_bf16_stats_nhwc";
+    ND_REQUIRE(chstats != nullptr && variant >= 0, fn, "chstats is null / the tile variant must be named");
+    return conv_bf16_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
+                          NI, H, W, N, 3, flags, variant, gnA, gnB, ld_gn, chstats, false, stream);
 }

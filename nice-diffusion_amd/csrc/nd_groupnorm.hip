@@ -349,26 +349,46 @@ static int check_src(const char* fn, const void* x0, int C0, int ldx0, const voi
 }
 
 // partial rows [img][row][0|1][C] (sum | sum of squares per channel) of a (two-source) tensor -> per-(image, group) sums
-// in float64, written (not added) in a fixed order: one block per image, thread g owns group g.
+// in float64, written (not added) in a fixed order: one block per (group, image); thread t adds the (row, channel) items
+// t, t + 128, ... of the group in float64, the 128 thread sums are added by a fixed tree in LDS.
 __global__ void __launch_bounds__(128)
     gn_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, double* stats, int G) {
-    const int img = blockIdx.x;
-    const int g = threadIdx.x;
-    if (g >= G) return;
+    __shared__ double red[2][128];
+    const int g = blockIdx.x, img = blockIdx.y;
     const int cpg = (C0 + C1) / G;
+    const int t = threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const bool second = c >= C0;
-        const float* pp = second ? p1 : p0;
-        const int Cs = second ? C1 : C0, rows = second ? rows1 : rows0, cc = second ? c - C0 : c;
-        for (int r = 0; r < rows; ++r) {
-            const float* q = pp + (((size_t)img * rows + r) * 2) * Cs + cc;
-            a += (double)q[0];
-            b += (double)q[Cs];
-        }
+    // the group's channels that live in the first / second source
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int n0 = c_lo < C0 ? ((c_hi < C0 ? c_hi : C0) - c_lo) : 0;      // channels c_lo .. c_lo + n0 - 1 of source 0
+    const int n1 = cpg - n0;                                              // then n1 channels of source 1
+    for (int i = t; i < rows0 * n0; i += 128) {
+        const int r = i / n0, cc = c_lo + (i - r * n0);
+        const float* q = p0 + (((size_t)img * rows0 + r) * 2) * C0 + cc;
+        a += (double)q[0];
+        b += (double)q[C0];
     }
-    stats[((size_t)img * G + g) * 2 + 0] = a;
-    stats[((size_t)img * G + g) * 2 + 1] = b;
+    const int c1_lo = (c_lo > C0 ? c_lo : C0) - C0;
+    for (int i = t; i < rows1 * n1; i += 128) {
+        const int r = i / n1, cc = c1_lo + (i - r * n1);
+        const float* q = p1 + (((size_t)img * rows1 + r) * 2) * C1 + cc;
+        a += (double)q[0];
+        b += (double)q[C1];
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    for (int w = 64; w > 0; w >>= 1) {
+        if (t < w) {
+            red[0][t] += red[0][t + w];
+            red[1][t] += red[1][t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        stats[((size_t)img * G + g) * 2 + 0] = red[0][0];
+        stats[((size_t)img * G + g) * 2 + 1] = red[1][0];
+    }
 }
 
 // pixel chunks per image of the statistics pass: enough blocks to fill the chip (~2048), at least 4 pixels per
@@ -511,7 +531,7 @@ extern "C" int nd_groupnorm_stats_from_partials(const float* p0, int C0, int row
     ND_REQUIRE(p0 && stats && NI > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 128 && (C0 + C1) % G == 0, fn,
                "bad arguments");
     if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
-    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
-                       rows0, C1 > 0 ? p1 : p0, C1, rows1, stats, G);
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(G, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
+                       rows0, C1 > 0 ? p1 : p0, C1, C1 > 0 ? rows1 : 0, stats, G);
     return check_launch(fn);
 }

@@ -86,6 +86,14 @@ def _epilogue_stats_enabled():
     return os.environ.get('ND_GN_EPILOGUE_STATS', '0') == '1'
 
 
+def _bf16_epilogue_stats():
+    """ND_BF16_EPILOGUE_STATS (default 1): bf16 3x3 convs whose output feeds a GroupNorm leave that norm's partial statistics
+    behind (nd_conv3x3_bf16_stats_nhwc + nd_groupnorm_stats_from_partials) where the plan builder measures that to be
+    cheaper than the statistics pass over the tensor; 0: always the statistics pass; 2: the epilogue form wherever a tile
+    variant offers it (tests)."""
+    return int(os.environ.get('ND_BF16_EPILOGUE_STATS', '1'))
+
+
 def _fuse_gn_mode():
     """0: never fold GroupNorm into the consumer conv; 1 (default): fold the affine-only norms (attention); 2: also fold
     norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
@@ -233,7 +241,7 @@ class UNetPlan:
         the fastest measured implementation is kept."""
         if self.bf16:
             return self._conv_bf16(src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label,
-                                   pad_c_to)
+                                   pad_c_to, want_stats=want_stats)
         gn = [None, None, 0]
         tmp = None
         if isinstance(src, Normed):
@@ -326,7 +334,8 @@ class UNetPlan:
                    'nd_repack_conv_weight_bf16')
         return out
 
-    def _conv_bf16(self, src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label, pad_c_to):
+    def _conv_bf16(self, src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label, pad_c_to,
+                   want_stats=False):
         tmp = None
         gn = [None, None, 0]
         if isinstance(src, Normed):
@@ -368,31 +377,71 @@ class UNetPlan:
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N, ksize, flags]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
-        var = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT)
+        stats_ok = want_stats and _bf16_epilogue_stats() and ksize == 3 and out.bf16 and out.ld == N
+        if stats_ok:
+            key = key + ('stats',)
+        var, with_stats = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT, out if stats_ok else None)
         wq = self._packed_bf16(weight, pad_c_to, self.lib.nd_conv_bf16_variant_layout(var))
         self.keep.append(wq)
         self.packed_floats += wq.numel() // 2
         head[W_SLOT] = wq.data_ptr()
-        self._emit(self.lib.nd_conv_bf16_nhwc, head + [var] + gn, label, flops=fl, variant=('bf16', var), ksize=ksize,
-                   shape=(NI, H, W, src.C + C1, N))
+        if with_stats:
+            # the conv's epilogue leaves the next GroupNorm's partial statistics behind (no pass over `out`)
+            rows = self.lib.nd_conv_bf16_stats_rows(NI, H, W, N, var)
+            assert rows > 0
+            ph = ('chpart', self._cs_floats)
+            out.cs = (ph, rows)
+            self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
+            self._emit(self.lib.nd_conv3x3_bf16_stats_nhwc, head[:-2] + [flags, var] + gn + [ph], label, flops=fl,
+                       variant=('bf16', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+        else:
+            self._emit(self.lib.nd_conv_bf16_nhwc, head + [var] + gn, label, flops=fl, variant=('bf16', var), ksize=ksize,
+                       shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         if tmp is not None:
             self._release(tmp)
         return out
 
-    def _pick_bf16(self, key, flops, head, gn, weight, pad_c_to, w_slot):
-        """Tile variant for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with ND_AUTOTUNE=0,
-        else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per shape."""
+    def _pick_bf16(self, key, flops, head, gn, weight, pad_c_to, w_slot, stats_out=None):
+        """(tile variant, with_stats) for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with
+        ND_AUTOTUNE=0, else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per
+        shape.  ``stats_out`` (the output Act of a conv feeding a GroupNorm): the variants that can leave the norm's partial
+        statistics behind are also measured doing so, and that form is taken when it beats the best plain variant plus the
+        measured statistics pass over the output."""
         if not _autotune_enabled() or flops < 2e8:
-            return -1
+            return -1, False
         ck = (self.device.index,) + key
         if ck in _TUNED:
-            return _TUNED[ck][1]
+            kind, v = _TUNED[ck]
+            return v, kind == 'bf16+stats'
         stream = self._stream()
         fn = self.lib.nd_conv_bf16_nhwc
+
+        def measure(f, args):
+            if not _CLOCK_SETTLED[0]:
+                t0 = time.time()
+                while time.time() - t0 < 1.0:
+                    for _ in range(8):
+                        f(*args, stream)
+                    torch.cuda.synchronize()
+                _CLOCK_SETTLED[0] = True
+            t = None
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(6):
+                    f(*args, stream)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / 6
+                t = ms if t is None else min(t, ms)
+            return t
+
         best, best_ms = -1, None
+        sbest, sbest_ms = -1, None
         packed = {}                                       # tuning copies of the weights, one per fragment layout
+        scratch = None
         for v in range(self.lib.nd_conv_bf16_num_variants()):
             lay = self.lib.nd_conv_bf16_variant_layout(v)
             if lay not in packed:
@@ -402,27 +451,36 @@ class UNetPlan:
             args = h + [v] + gn
             if fn(*args, stream) != 0:
                 continue                                  # this tile shape does not fit the problem
-            if not _CLOCK_SETTLED[0]:
-                t0 = time.time()
-                while time.time() - t0 < 1.0:
-                    for _ in range(8):
-                        fn(*args, stream)
-                    torch.cuda.synchronize()
-                _CLOCK_SETTLED[0] = True
-            t = None
-            for _ in range(2):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(6):
-                    fn(*args, stream)
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1) / 6
-                t = ms if t is None else min(t, ms)
+            t = measure(fn, args)
             if best_ms is None or t < best_ms:
                 best, best_ms = v, t
-        _TUNED[ck] = ('bf16', best)
-        return best
+            if stats_out is not None:
+                o = stats_out
+                rows = self.lib.nd_conv_bf16_stats_rows(o.NI, o.H, o.W, o.C, v)
+                if rows > 0:
+                    need = o.NI * rows * 2 * o.C
+                    if scratch is None or scratch.numel() < need:
+                        scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+                    sargs = h[:-2] + [h[-1], v] + gn + [scratch.data_ptr()]
+                    if self.lib.nd_conv3x3_bf16_stats_nhwc(*sargs, stream) == 0:
+                        t = measure(self.lib.nd_conv3x3_bf16_stats_nhwc, sargs)
+                        if sbest_ms is None or t < sbest_ms:
+                            sbest, sbest_ms = v, t
+        choice = ('bf16', best)
+        if sbest >= 0:
+            o = stats_out
+            nblk = self.lib.nd_groupnorm_stats_blocks(o.NI, o.H * o.W, o.C, self.dt)
+            part = torch.empty(o.NI * nblk * GN_GROUPS * 2, dtype=torch.float64, device=self.device)
+            pargs = [o.ptr, o.C, o.ld, None, 0, 0, None, 0, part.data_ptr(), o.NI, o.H * o.W, GN_GROUPS, self.dt]
+            pass_ms = measure(self.lib.nd_groupnorm_stats_nhwc, pargs)
+            fold = torch.empty(o.NI * GN_GROUPS * 2, dtype=torch.float64, device=self.device)
+            rows = self.lib.nd_conv_bf16_stats_rows(o.NI, o.H, o.W, o.C, sbest)
+            fargs = [scratch.data_ptr(), o.C, rows, None, 0, 0, fold.data_ptr(), o.NI, GN_GROUPS]
+            fold_ms = measure(self.lib.nd_groupnorm_stats_from_partials, fargs)
+            if sbest_ms + fold_ms < best_ms + pass_ms or _bf16_epilogue_stats() == 2:
+                choice = ('bf16+stats', sbest)
+        _TUNED[ck] = choice
+        return choice[1], choice[0] == 'bf16+stats'
 
     def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
         """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct

@@ -237,6 +237,105 @@ def test_conv_bf16_fused_groupnorm(ksize, silu):
     assert rc == -1
 
 
+@pytest.mark.parametrize('B,C0,C1,N,H,W,opts', [
+    (2, 64, 0, 96, 16, 16, ''), (2, 64, 32, 72, 32, 32, 'rowbias,residual'), (3, 40, 0, 256, 20, 12, 'residual'),
+    (1, 64, 0, 64, 64, 64, 'gn'), (2, 64, 0, 96, 16, 16, 'res_up'), (2, 32, 0, 48, 32, 32, 'up')])
+def test_conv3x3_bf16_epilogue_statistics(B, C0, C1, N, H, W, opts):
+    """nd_conv3x3_bf16_stats_nhwc: bit-identical output to nd_conv_bf16_nhwc with the same variant, plus partial per-channel
+    sums / sums of squares of the bf16 values it stored; nd_groupnorm_stats_from_partials folds them into what the
+    statistics pass over the output computes (same numbers up to fp32 partial sums of <= 256 values), also for a
+    two-source consumer; repeated launches give the same bits (no atomics)."""
+    C = C0 + C1
+    up = 'up' in opts.split(',')
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    xa = rnd(B, C0, Hs, Ws, seed=1)
+    xb = rnd(B, C1, Hs, Ws, seed=2) if C1 else None
+    w = rnd(N, C, 3, 3, seed=3, scale=0.05)
+    b, rb = rnd(N, seed=4), rnd(B, N, seed=5)
+    res_up = 'res_up' in opts
+    res = rnd(B, N, H // 2 if res_up else H, W // 2 if res_up else W, seed=6)
+    xad, xbd = nhwc_bf(xa), (nhwc_bf(xb) if C1 else None)
+    wd, bd, rbd, resd = pack_bf(w), b.to(DEV), rb.to(DEV), nhwc_bf(res)
+    use_rb, use_res = 'rowbias' in opts, ('residual' in opts or res_up)
+    flags = (_hip.CONV_IN_UP2X if up else 0) | (_hip.CONV_RES_UP2X if res_up else 0)
+    gn = [None, None, 0]
+    if 'gn' in opts:
+        cA, cB = (1 + 0.2 * rnd(B, C, seed=7)).to(DEV).contiguous(), (0.1 * rnd(B, C, seed=8)).to(DEV).contiguous()
+        gn = [cA.data_ptr(), cB.data_ptr(), C]
+        flags |= _hip.CONV_GN_SILU
+    head = [xad.data_ptr(), C0, C0, None if not C1 else xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
+            rbd.data_ptr() if use_rb else None, N if use_rb else 0, resd.data_ptr() if use_res else None, N if use_res else 0]
+    ran = 0
+    for v in range(lib().nd_conv_bf16_num_variants()):
+        rows = lib().nd_conv_bf16_stats_rows(B, H, W, N, v)
+        out0 = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        rc0 = lib().nd_conv_bf16_nhwc(*head, out0.data_ptr(), N, B, H, W, N, 3, flags, v, *gn, st())
+        if rows <= 0:
+            dummy = torch.empty(16, device=DEV)
+            assert lib().nd_conv3x3_bf16_stats_nhwc(*head, out0.data_ptr(), N, B, H, W, N, flags, v, *gn, dummy.data_ptr(), st()) != 0
+            continue
+        if rc0 != 0:
+            continue
+        ran += 1
+        out1 = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        ps = torch.full((B * rows * 2 * N,), float('nan'), dtype=torch.float32, device=DEV)
+        _hip.check(lib().nd_conv3x3_bf16_stats_nhwc(*head, out1.data_ptr(), N, B, H, W, N, flags, v, *gn, ps.data_ptr(), st()))
+        assert torch.equal(out0.view(torch.int16), out1.view(torch.int16)), v
+        assert not torch.isnan(ps).any(), v
+        o = out1.view(B, H * W, N).double()
+        pp = ps.view(B, rows, 2, N).double().sum(1)
+        assert (pp[:, 0] - o.sum(1)).abs().max().item() <= 1e-5 * max(1.0, o.abs().sum(1).max().item()), v
+        assert (pp[:, 1] - (o * o).sum(1)).abs().max().item() <= 1e-5 * (o * o).sum(1).max().item(), v
+        if N % 32 == 0:
+            a = torch.empty(B * 64, dtype=torch.float64, device=DEV)
+            _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), N, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
+            ref = torch.stack([o.view(B, H * W, 32, N // 32).sum((1, 3)), (o * o).view(B, H * W, 32, N // 32).sum((1, 3))], -1)
+            assert (a.view(B, 32, 2) - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), v
+            # consumer reading cat([out, out]) (the up path's skip concatenation; groups straddle the seam when N/16 is odd)
+            a2 = torch.empty(B * 64, dtype=torch.float64, device=DEV)
+            _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), N, rows, ps.data_ptr(), N, rows, a2.data_ptr(), B, 32, st()))
+            o2 = torch.cat([o, o], 2)
+            ref2 = torch.stack([o2.view(B, H * W, 32, N // 16).sum((1, 3)), (o2 * o2).view(B, H * W, 32, N // 16).sum((1, 3))], -1)
+            assert (a2.view(B, 32, 2) - ref2).abs().max().item() <= 1e-5 * ref2.abs().max().item(), v
+        ps2 = torch.empty_like(ps)
+        _hip.check(lib().nd_conv3x3_bf16_stats_nhwc(*head, out1.data_ptr(), N, B, H, W, N, flags, v, *gn, ps2.data_ptr(), st()))
+        assert torch.equal(ps, ps2), v
+    assert ran >= 3
+
+
+@pytest.mark.parametrize('base', ['adagn_updown', 'plain_convres_legacy'])
+def test_bf16_forward_with_epilogue_statistics_matches_statistics_pass(monkeypatch, base):
+    """The plan builder's choice (ND_BF16_EPILOGUE_STATS: 1 = where measured faster, 2 = wherever possible) only moves
+    where a GroupNorm's sums are formed: the forward with conv-epilogue statistics equals the forward with the statistics
+    pass to within a few bf16 roundings, and the epilogue form is actually taken on a model whose convs are big enough to
+    be tuned (AdaGN + resblock up/down, and plain GN with the embedding added in the conv epilogue + conv resampling)."""
+    from nicediffusion import _engine
+    cfg = dict(TINY_CFGS[base], resolution=32, model_channels=64, attention_resolutions=(16,))
+    B = 8
+    x = rnd(B, 3, 32, 32, seed=3).to(DEV)
+    t = torch.tensor([5, 100, 300, 999, 0, 1, 2, 3], device=DEV)
+    y = (torch.arange(B, device=DEV) % 10) if cfg.get('num_classes') else None
+    outs = {}
+    for mode in ('2', '0'):
+        monkeypatch.setenv('ND_BF16_EPILOGUE_STATS', mode)
+        _engine._TUNED.clear()
+        m = build(cfg)
+        outs[mode] = m(x, t, y=y).float().cpu()
+        plan = next(iter(m._plans.values()))
+        used = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_conv3x3_bf16_stats_nhwc')
+        folds = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_groupnorm_stats_from_partials')
+        if mode == '0':
+            assert used == 0 and folds == 0
+        else:
+            print('epilogue statistics on %d convs, %d folds' % (used, folds))
+            assert used > 0 and folds > 0
+    _engine._TUNED.clear()
+    assert torch.isfinite(outs['2']).all()
+    rms, mx = _errs(outs['2'], outs['0'])
+    print('epilogue statistics vs statistics pass: rms %.2e max %.2e' % (rms, mx))
+    assert rms < 1e-2 and mx < 4e-2
+
+
 def test_conv_bf16_long_k_full_size_layer():
     """A full-size layer of the 128x128 preset (two-source 512+256 -> 256 at 64x64, B=2): long contraction (K = 6912),
     every variant that fits gives the same result as the cost model's pick to within output rounding."""
