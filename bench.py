@@ -117,12 +117,16 @@ def _traffic_table():
         return None
 
 
+CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
+            'nd_conv3x3_bf16_stats_nhwc')
+
+
 def roofline_from(rows, lib, dtype='fp32', esize=4):
     """Dominant kernel = the conv kernel instantiation with the largest total time in one forward.  `achieved` / `frac`
     are EXECUTED matrix-pipe flops per second (the Winograd kernels execute 4/9 of the direct-convolution flops);
     the algorithmic (direct-convolution) rate is kept under `algorithmic_equivalent`."""
     import ctypes
-    conv_fns = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc')
+    conv_fns = CONV_FNS
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
 
     def executed(r):
@@ -199,7 +203,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
 def class_breakdown(rows):
     out = {}
     for r in rows:
-        k = r['label'].split('.')[0] if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc') else r['label']
+        k = r['label'].split('.')[0] if r['fn'] not in CONV_FNS else r['label']
         if r['fn'].startswith('nd_groupnorm'):
             k = 'groupnorm_' + r['fn'].split('_')[2]
         out[k] = out.get(k, 0.0) + r['ms']
