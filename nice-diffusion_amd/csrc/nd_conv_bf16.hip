@@ -56,20 +56,33 @@ struct ConvArgsH {
     int cs_rows;
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+// Eight independent sums over the 32 lanes that share lane >> 5, in a fixed order, valid in lanes 16..31 (48..63) of the
+// group: xor 1, xor 2 (quad permutes), mirror within 8, mirror within 16, then lane 15 of the even row broadcast into
+// the odd row (row_bcast:15).  DPP operands on the adds themselves; the eight chains are interleaved so that a register
+// is read by a DPP operand eight instructions after it was written (the hardware wants two wait states; hipcc does not
+// fold v_mov_dpp into a float add and pads every move with s_nop).
+#define ND_DPP8(ctrl)                                        \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                    \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                    \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                    \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                    \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                    \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                    \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                    \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"
+__device__ __forceinline__ void sum8_over_32_lanes(f32x4& a, f32x4& b) {
+    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
+    asm volatile("s_nop 1\n"
+                 ND_DPP8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 ND_DPP8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 ND_DPP8("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 ND_DPP8("row_mirror row_mask:0xf bank_mask:0xf")
+                 ND_DPP8("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    a[0] = v0; a[1] = v1; a[2] = v2; a[3] = v3;
+    b[0] = v4; b[1] = v5; b[2] = v6; b[3] = v7;
 }
-// sum over the 32 lanes that share lane >> 5, in a fixed order, result in every lane: xor 1, xor 2 (quad permutes), mirror
-// within 8, mirror within 16 (DPP, folded into the adds), then lane ^ 16 by ds_swizzle (no LDS memory involved)
-__device__ __forceinline__ float sum_over_32_lanes(float x) {
-    x += dpp_move<0xB1>(x);
-    x += dpp_move<0x4E>(x);
-    x += dpp_move<0x141>(x);
-    x += dpp_move<0x140>(x);
-    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-    return x;
-}
+#undef ND_DPP8
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     union { f32x4 f; bf16x8 h; } u;
@@ -397,74 +410,6 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #endif
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
-    if constexpr (STATS) {
-        // the same epilogue, channel groups outermost, which also leaves per-channel sums / sums of squares of the bf16
-        // values it stores (the next GroupNorm's statistics) in row (pixel tile, wave row) of p.chstats.  Host-checked:
-        // one image per block, N % 4 == 0, vector-friendly strides, bf16 output.
-        int opix[TM], rpix[TM];
-        bool ok[TM];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int m = (wm * TM + mi) * 32 + l31;
-            const int oy = oy0 + ((m >> p.twl) & (TH - 1));
-            const int ox = ox0 + (m & (TW - 1));
-            ok[mi] = oy < p.H && ox < p.W;
-            opix[mi] = (img0 * p.H + oy) * p.W + ox;
-            rpix[mi] = p.res_up ? (img0 * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1) : opix[mi];
-        }
-        const float* rb = p.rowbias ? p.rowbias + (size_t)img0 * p.ld_rowbias : nullptr;
-        float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
-                const bool nok = n + 3 < p.N;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rbv = {0.f, 0.f, 0.f, 0.f};      // added in the plain epilogue's order
-                if (nok) {
-                    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (rb) rbv = *reinterpret_cast<const f32x4*>(rb + n);
-                }
-                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    if (nok && ok[mi]) {
-                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
-                                   acc[mi][ni][4 * g4 + 3]};
-                        if (p.bias) v += bv;
-                        if (rb) v += rbv;
-                        if (p.res) {
-                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + (size_t)rpix[mi] * p.ldr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                        }
-                        if (p.silu_out) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
-                        }
-                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + (size_t)opix[mi] * p.ldo + n) = o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float r = (float)o[e];
-                            s1[e] += r;
-                            s2[e] += r * r;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1[e] = sum_over_32_lanes(s1[e]);
-                    s2[e] = sum_over_32_lanes(s2[e]);
-                }
-                if (nok && l31 == 0) {
-                    *reinterpret_cast<f32x4*>(cs + n) = s1;
-                    *reinterpret_cast<f32x4*>(cs + p.N + n) = s2;
-                }
-            }
-        }
-        return;
-    }
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -505,6 +450,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         } else {
                             const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                             *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
+                            if constexpr (STATS) {      // keep what was stored: the statistics below are those of the bf16 tensor
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g4 + e] = (float)o[e];
+                            }
                         }
                     } else {
 #pragma unroll
@@ -520,6 +469,38 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                             }
                         }
                     }
+                }
+            }
+        } else if constexpr (STATS) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+    }
+    if constexpr (STATS) {
+        // per-channel sums / sums of squares of the stored values over this wave's TM x 32 pixels -> row (pixel tile, wave
+        // row) of p.chstats.  Host-checked: one image per block, N % 4 == 0, vector-friendly strides, bf16 output.
+        float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = acc[mi][ni][4 * g4 + e];
+                        s1[e] += r;
+                        s2[e] += r * r;
+                    }
+                }
+                sum8_over_32_lanes(s1, s2);
+                if (n + 3 < p.N && l31 == 31) {
+                    *reinterpret_cast<f32x4*>(cs + n) = s1;
+                    *reinterpret_cast<f32x4*>(cs + p.N + n) = s2;
                 }
             }
         }

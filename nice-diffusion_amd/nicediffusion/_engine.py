@@ -10,6 +10,7 @@ import ctypes
 import json
 import math
 import os
+import sys
 import time
 
 import torch
@@ -477,6 +478,9 @@ class UNetPlan:
             rows = self.lib.nd_conv_bf16_stats_rows(o.NI, o.H, o.W, o.C, sbest)
             fargs = [scratch.data_ptr(), o.C, rows, None, 0, 0, fold.data_ptr(), o.NI, GN_GROUPS]
             fold_ms = measure(self.lib.nd_groupnorm_stats_from_partials, fargs)
+            if os.environ.get('ND_TUNE_VERBOSE', '0') == '1':
+                print('[tune] %s: plain v%d %.4f ms + pass %.4f | stats v%d %.4f ms + fold %.4f' %
+                      (key[1:7], best, best_ms, pass_ms, sbest, sbest_ms, fold_ms), file=sys.stderr)
             if sbest_ms + fold_ms < best_ms + pass_ms or _bf16_epilogue_stats() == 2:
                 choice = ('bf16+stats', sbest)
         _TUNED[ck] = choice
