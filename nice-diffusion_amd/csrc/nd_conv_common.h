@@ -88,6 +88,10 @@ struct TilePlan {
     long padded;   // padded pixel count
 };
 
+struct ConvArgs;
+// conv_winow_kernel (nd_conv_winograd_wave.hip), launched by nd_conv3x3_winograd_nhwc's variant 11
+int launch_winow(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
+
 static inline int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

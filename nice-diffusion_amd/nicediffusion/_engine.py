@@ -544,6 +544,11 @@ class UNetPlan:
                 if os.environ.get('ND_WINO_PERSISTENT', '0') != '1' and \
                         self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel':
                     continue
+                # the whole-transform-per-wave form (4 waves, output transform in registers) gives the same bits too and
+                # measures 20-40 % slower: one wave per SIMD cannot hide its own patch reads
+                if os.environ.get('ND_WINO_WAVE', '0') != '1' and \
+                        self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_winow_kernel':
+                    continue
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms

@@ -133,8 +133,11 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
         rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                             None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st())
-        if rc != 0:      # only the persistent form may decline a shape (odd number of 32-channel chunks)
-            assert lib().nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
+        if rc != 0:      # the persistent form declines an odd number of 32-channel chunks, the 256-pixel whole-transform-per-wave
+            # form maps so small that 64 tiles span more than 416 halo pixels
+            name = lib().nd_conv_winograd_variant_name(v)
+            assert (name == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()) or \
+                (name == b'nd::conv_winow_kernel' and 'no tiling fits' in _hip.last_error() and H * W <= 16), (name, _hip.last_error())
             continue
         got = from_nhwc(out, B, H, W, Cout)
         assert torch.isfinite(got).all(), v
@@ -145,13 +148,15 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
     assert rc == -1 and 'even' in _hip.last_error()
 
 
+@pytest.mark.parametrize('other', [b'nd::conv_wino16p_kernel', b'nd::conv_winow_kernel'])
 @pytest.mark.parametrize('B,Cin,Cout,H,W', [(8, 64, 192, 64, 64), (64, 128, 96, 8, 8), (3, 192, 200, 32, 32), (1, 64, 96, 16, 16)])
-def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W):
+def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W, other):
     """conv_wino16p_kernel (one block per CU walking several tiles, the next tile's first chunk fetched during the current
-    tile's last one) gives the SAME BITS as conv_wino16_kernel: several tiles per block, N tails, two-source input,
-    per-image bias and residual included."""
+    tile's last one) and conv_winow_kernel (all 16 transform positions in one wave, output transform in registers) give
+    the SAME BITS as conv_wino16_kernel: several tiles per block, N tails, two-source input, per-image bias and residual
+    included."""
     names = [lib().nd_conv_winograd_variant_name(v) for v in range(lib().nd_conv_winograd_num_variants())]
-    v1, vp = names.index(b'nd::conv_wino16_kernel<1>'), names.index(b'nd::conv_wino16p_kernel')
+    v1, vp = names.index(b'nd::conv_wino16_kernel<1>'), names.index(other)
     C0 = Cin // 2
     xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, Cin - C0, H, W, seed=2)
     w, b = rnd(Cout, Cin, 3, 3, seed=3, scale=0.05), rnd(Cout, seed=4)
