@@ -56,34 +56,6 @@ struct ConvArgsH {
     int cs_rows;
 };
 
-// Eight independent sums over the 32 lanes that share lane >> 5, in a fixed order, valid in lanes 16..31 (48..63) of the
-// group: xor 1, xor 2 (quad permutes), mirror within 8, mirror within 16, then lane 15 of the even row broadcast into
-// the odd row (row_bcast:15).  DPP operands on the adds themselves; the eight chains are interleaved so that a register
-// is read by a DPP operand eight instructions after it was written (the hardware wants two wait states; hipcc does not
-// fold v_mov_dpp into a float add and pads every move with s_nop).
-#define ND_DPP8(ctrl)                                        \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                    \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                    \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                    \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                    \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                    \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                    \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                    \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"
-__device__ __forceinline__ void sum8_over_32_lanes(f32x4& a, f32x4& b) {
-    float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
-    asm volatile("s_nop 1\n"
-                 ND_DPP8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 ND_DPP8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 ND_DPP8("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 ND_DPP8("row_mirror row_mask:0xf bank_mask:0xf")
-                 ND_DPP8("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
-    a[0] = v0; a[1] = v1; a[2] = v2; a[3] = v3;
-    b[0] = v4; b[1] = v5; b[2] = v6; b[3] = v7;
-}
-#undef ND_DPP8
-
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     union { f32x4 f; bf16x8 h; } u;
     u.f = v;

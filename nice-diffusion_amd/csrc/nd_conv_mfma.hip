@@ -633,6 +633,8 @@ static const Variant kVariants[] = {
     {2, 2, 2, 2, 3},   // 10: 128 x 128
     {2, 2, 1, 3, 3},   // 11:  64 x 192
     {4, 1, 2, 3, 2},   // 12: 256 x  96
+    // GEMM form (gemm_f32_kernel, nd_gemm_f32.hip): both operands through three LDS stages filled by LDS-DMA
+    {4, 2, 2, 2, 1},   // 13: 256 x 128, 8 waves
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr int kFirstStream = 9;
@@ -851,6 +853,9 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
         case 10: return launch_stream<2, 2, 2, 2, 3>(a, grid, s);
         case 11: return launch_stream<2, 2, 1, 3, 3>(a, grid, s);
         case 12: return launch_stream<4, 1, 2, 3, 2>(a, grid, s);
+        case 13:
+            a.zero = w + (nd_conv_weight_floats(N, C0 + C1, ksize) - 4);      // 16 bytes of the packed weights' zero padding chunk
+            return launch_gemm_f32(a, grid, s);
     }
     return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
 }

@@ -687,14 +687,24 @@ __global__ void __launch_bounds__(1024, 4)
                 // instead of the whole tensor.
                 f32x4 sq = fin * fin;
                 const int gl = 1 << (thl2 + twl2);          // tiles (= lanes of a half-wave) per image
-                for (int m = 1; m < gl; m <<= 1) {
+                bool writer;
+                if (gl == 32) {                             // DPP adds, no LDS traffic (nd_conv_common.h); total in lanes 16..31
+                    sum8_over_32_lanes(fin, sq);
+                    writer = l31 == 31;
+                } else if (gl == 16) {
+                    sum8_over_16_lanes(fin, sq);
+                    writer = (l31 & 15) == 0;
+                } else {
+                    for (int m = 1; m < gl; m <<= 1) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        fin[c] += __shfl_xor(fin[c], m);
-                        sq[c] += __shfl_xor(sq[c], m);
+                        for (int c = 0; c < 4; ++c) {
+                            fin[c] += __shfl_xor(fin[c], m);
+                            sq[c] += __shfl_xor(sq[c], m);
+                        }
                     }
+                    writer = (l31 & (gl - 1)) == 0;
                 }
-                if ((l31 & (gl - 1)) == 0 && img < p.NI && nb < p.N) {
+                if (writer && img < p.NI && nb < p.N) {
                     const int mb = (p.nibl == 0) ? (ty * p.tiles_x + tx) : 0;
                     float* ps = p.chstats + ((((size_t)img * p.mbi + mb) * 4 + (wave >> 2)) * 2) * p.N + nb;
                     if (nb + 3 < p.N && (p.N & 3) == 0) {

@@ -11,8 +11,18 @@ SHAPES = [('square 8192^3', 8192, 8192, 8192),
           ('128x128x32 img, 256->256 3x3 (M=524288,K=2304,N=256)', 524288, 256, 2304),
           ('64x64x32 img, 512->512 3x3 (M=131072,K=4608,N=512)', 131072, 512, 4608),
           ('64x64x64 img, 192->192 3x3 (M=262144,K=1728,N=192)', 262144, 192, 1728),
-          ('32x32x64 img, 384->384 3x3 (M=65536,K=3456,N=384)', 65536, 384, 3456)]
-for dt, name in ((torch.bfloat16, 'bf16'), (torch.float32, 'fp32')):
+          ('32x32x64 img, 384->384 3x3 (M=65536,K=3456,N=384)', 65536, 384, 3456),
+          # the 1x1 convolutions of configs[1] (short K)
+          ('32x32x64 img, qkv 384->1152 1x1 (M=65536,K=384,N=1152)', 65536, 1152, 384),
+          ('32x32x64 img, proj 384->384 1x1', 65536, 384, 384),
+          ('64x64x64 img, skip 576->192 1x1', 262144, 192, 576),
+          ('16x16x64 img, qkv 576->1728 1x1', 16384, 1728, 576),
+          ('8x8x64 img, qkv 768->2304 1x1', 4096, 2304, 768)]
+import sys
+DTYPES = ((torch.bfloat16, 'bf16'), (torch.float32, 'fp32'))
+if len(sys.argv) > 1:
+    DTYPES = tuple(d for d in DTYPES if d[1] in sys.argv[1:])
+for dt, name in DTYPES:
     for label, M, N, K in SHAPES:
         a = torch.randn(M, K, device=dev, dtype=dt)
         b = torch.randn(K, N, device=dev, dtype=dt)
