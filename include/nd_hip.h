@@ -155,6 +155,16 @@ int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1,
                                const void* residual, int ldr, void* out, int ldo,
                                int NI, int H, int W, int N, int flags, int variant,
                                const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream);
+/* The same convolution split over K for layers with too few output tiles to fill the chip (8x8 / 16x16 maps): block row s
+ * of `splits` computes a range of whole input-channel chunks and leaves raw fp32 partials in `workspace` (splits * NI*H*W * N
+ * floats), a second kernel adds them in split order (deterministic) with bias / rowbias / residual / SiLU and writes bf16.
+ * Plain bf16 output only: no fused GroupNorm, output statistics, 2x-upsampled reads or LDS-DMA variants; the tile variant
+ * must be named; fewer splits are used when the layer has fewer chunks (error if that leaves one). */
+int nd_conv_bf16_splitk_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                             const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                             const void* residual, int ldr, void* out, int ldo,
+                             int NI, int H, int W, int N, int ksize, int flags, int variant, int splits,
+                             float* workspace, nd_stream_t stream);
 /* Kernel behind a tile variant ("nd::conv_bf16_kernel", "nd::conv_bf16s_kernel", "nd::conv_bf16w_kernel",
  * "nd::gemm_bf16_kernel"); "" for an unknown variant. */
 const char* nd_conv_bf16_variant_name(int variant);

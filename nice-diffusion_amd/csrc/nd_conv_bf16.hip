@@ -54,7 +54,40 @@ struct ConvArgsH {
     // one row per (pixel tile of the image, wave row), every row written by every launch
     float* chstats;
     int cs_rows;
+    // split over K (gridDim.y = ksplit > 1): block row s computes channels [s * kchunks * 64, ...) only and writes its raw
+    // fp32 accumulators to out + s * ws_stride floats (out is then the workspace; bias / residual / activation are applied
+    // by splitk_reduce_kernel, which adds the ksplit partials in order)
+    int ksplit, kchunks;
+    long ws_stride;
 };
+
+// The arguments of split s, derived from the whole problem's: a convolution over the channel sub-range of that split.
+__device__ __forceinline__ void split_k_args(ConvArgsH& p, int s, int taps) {
+    const int span = p.kchunks * 64;
+    const int c_begin = s * span;
+    int nc = p.NC64 - s * p.kchunks;
+    nc = nc < p.kchunks ? nc : p.kchunks;
+    p.w += (size_t)s * p.kchunks * ((size_t)p.NT32 * taps * 4 * 512);      // both fragment layouts: NT32 * taps * 4 KiB-fragments per chunk
+    if (c_begin < p.C0) {
+        p.x0 += c_begin;
+        const int left0 = p.C0 - c_begin;
+        if (left0 >= span) {
+            p.C0 = span;
+            p.C1 = 0;
+        } else {
+            p.C0 = left0;
+            p.C1 = (p.C1 < span - left0) ? p.C1 : span - left0;
+        }
+    } else {
+        const int off1 = c_begin - p.C0;
+        p.x0 = p.x1 + off1;
+        p.ldx0 = p.ldx1;
+        p.C0 = (p.C1 - off1 < span) ? p.C1 - off1 : span;
+        p.C1 = 0;
+    }
+    p.NC64 = nc;
+    p.out = static_cast<float*>(p.out) + (size_t)s * p.ws_stride;
+}
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     union { f32x4 f; bf16x8 h; } u;
@@ -64,7 +97,9 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
 
 template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
-    conv_bf16_kernel(const ConvArgsH p) {
+    conv_bf16_kernel(const ConvArgsH pin) {
+    ConvArgsH p = pin;
+    if (pin.ksplit > 1) split_k_args(p, blockIdx.y, TAPS);
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -489,7 +524,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 //   C/D                     lane (pixel = lane & 15): registers 0..3 = output channels 4*kq .. 4*kq + 3
 template <int WM, int WN, int TM, int TN, int TAPS>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
-    conv_bf16s_kernel(const ConvArgsH p) {
+    conv_bf16s_kernel(const ConvArgsH pin) {
+    ConvArgsH p = pin;
+    if (pin.ksplit > 1) split_k_args(p, blockIdx.y, TAPS);
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 16;      // TM, TN count 16-wide tiles of v_mfma_f32_16x16x32_bf16
     constexpr int BN = WN * TN * 16;
@@ -1317,6 +1354,34 @@ __global__ void __launch_bounds__(512, 2)
     }
 }
 
+// Split-K second pass: out[m][n] = bf16(sum_s ws[s][m][n] + bias[n] + rowbias[img(m)][n] + residual[m][n]) (SiLU last), the
+// partials added in split order: deterministic.  One thread per 4 channels.
+__global__ void __launch_bounds__(256)
+    splitk_reduce_kernel(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
+                         int ld_rowbias, int hw, const __bf16* res, int ldr, __bf16* out, int ldo, int silu) {
+    const int nq = N >> 2;
+    const long total = M * nq;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long m = it / nq;
+        const int n = (int)(it - m * nq) << 2;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (size_t)s * ws_stride + m * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (rowbias) v += *reinterpret_cast<const f32x4*>(rowbias + (m / hw) * ld_rowbias + n);
+        if (res) {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+        }
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(out + m * ldo + n) = o;
+    }
+}
+
 // fp32 OIHW [N][C][k][k] (also Conv1d [N][C][1], Linear [N][C]) -> bf16 fragment order
 //   out[((((c64*NT32 + ntile)*taps + tap)*4 + ks)*64 + lane)*8 + j] = bf16(w[n = ntile*32 + (lane&31)][c = c64*64 + ks*16 + (lane>>5)*8 + j][tap])
 // zero for n >= N, c >= C and for the padding chunks.
@@ -1492,7 +1557,7 @@ static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS, STATS>;
     static bool attr_set[kMaxDevices] = {};
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WM * WN * 64), lds, s, a);
     return check_launch("nd_conv_bf16_nhwc");
 }
 
@@ -1510,7 +1575,7 @@ static int launch_s(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     auto kern = conv_bf16s_kernel<WM, WN, TM, TN, TAPS>;
     static bool attr_set[kMaxDevices] = {};
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WM * WN * 64), lds, s, a);
     return check_launch("nd_conv_bf16_nhwc");
 }
 
@@ -1635,7 +1700,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
                           const void* residual, int ldr, void* out, int ldo,
                           int NI, int H, int W, int N, int ksize, int flags, int variant,
                           const float* gnA, const float* gnB, int ld_gn, float* chstats, bool stats_rows_only,
-                          nd_stream_t stream) {
+                          nd_stream_t stream, int splits = 1, float* workspace = nullptr) {
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -1679,15 +1744,33 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     ConvArgsH a;
     a.chstats = chstats;
     a.cs_rows = tp.tiles_x * tp.tiles_y * V.wm;
+    a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;
+    const int nc64 = (C0 + C1 + 63) / 64;
+    if (splits > 1) {
+        // blocks [.., s] run the channel range of split s and leave raw fp32 partials in the workspace; splitk_reduce_kernel
+        // finishes the layer.  Chunk ranges are whole LDS chunks (64 channels for 3x3, 128 for 1x1).
+        ND_REQUIRE(workspace != nullptr && !V.ldsw && !chstats && gnA == nullptr, fn,
+                   "split-K: needs a workspace; not with the LDS-DMA forms, output statistics or a fused GroupNorm");
+        ND_REQUIRE(!(flags & (ND_CONV_IN_UP2X | ND_CONV_RES_UP2X | ND_CONV_OUT_F32)) && (N & 3) == 0 && (ldo & 3) == 0 &&
+                   (!residual || (ldr & 3) == 0) && (!rowbias || (ld_rowbias & 3) == 0), fn,
+                   "split-K: plain bf16 output, N and strides multiples of 4, no 2x-upsampled reads");
+        const int unit = taps == 9 ? 1 : 2;
+        int kc = (nc64 + splits - 1) / splits;
+        kc = (kc + unit - 1) / unit * unit;
+        const int S = (nc64 + kc - 1) / kc;
+        ND_REQUIRE(S > 1, fn, "split-K: too few input channels for that many splits");
+        a.ksplit = S; a.kchunks = kc; a.ws_stride = M * N;
+    }
     a.x0 = static_cast<const __bf16*>(x0);
     a.x1 = (C1 > 0) ? static_cast<const __bf16*>(x1) : a.x0;
     a.w = static_cast<const __bf16*>(w);
     a.bias = bias; a.rowbias = rowbias; a.res = static_cast<const __bf16*>(residual); a.out = out;
+    if (a.ksplit > 1) { a.bias = nullptr; a.rowbias = nullptr; a.res = nullptr; a.out = workspace; }
     a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
     a.NI = pNI; a.H = pH; a.W = pW;
     a.up = up; a.res_up = res_up;
     a.Hs = pH >> up; a.Ws = pW >> up;
-    a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
+    a.N = N; a.ldo = (a.ksplit > 1) ? N : ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
     a.NT32 = (N + 31) / 32;
     a.NC64 = (C0 + C1 + 63) / 64;
     a.thl = tp.thl; a.twl = tp.twl; a.nibl = tp.nibl;
@@ -1697,6 +1780,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * 2);
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
+    if (a.ksplit > 1) { a.silu_out = 0; a.out_f32 = 1; }
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     size_t lds_gn = 0;
     if (gnA) {
@@ -1736,7 +1820,15 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     }
     const size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
     if (chstats) return dispatch_h_stats(v, a, grid, lds, s);
-    return (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
+    const int rc = (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
+    if (rc != ND_OK || a.ksplit <= 1) return rc;
+    const long quads = M * (N >> 2);
+    long rg = (quads + 255) / 256;
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)rg), dim3(256), 0, s, workspace, a.ksplit, a.ws_stride, M, N, bias, rowbias,
+                       ld_rowbias, H * W, static_cast<const __bf16*>(residual), ldr, static_cast<__bf16*>(out), ldo,
+                       (flags & ND_CONV_SILU_OUT) ? 1 : 0);
+    return check_launch(fn);
 }
 
 extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
@@ -1746,6 +1838,18 @@ extern "C" int nd_conv_bf16_nhwc(const void* x0, int C0, int ldx0, const void* x
                                  const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     return conv_bf16_impl("nd_conv_bf16_nhwc", x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
                           NI, H, W, N, ksize, flags, variant, gnA, gnB, ld_gn, nullptr, false, stream);
+}
+
+extern "C" int nd_conv_bf16_splitk_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                        const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                        const void* residual, int ldr, void* out, int ldo,
+                                        int NI, int H, int W, int N, int ksize, int flags, int variant, int splits,
+                                        float* workspace, nd_stream_t stream) {
+    const char* fn = "nd_conv_bf16_splitk_nhwc";
+    ND_REQUIRE(splits >= 2 && splits <= 16 && workspace != nullptr && variant >= 0, fn,
+               "2..16 splits, a workspace of splits * NI*H*W * N floats, and a named tile variant");
+    return conv_bf16_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
+                          NI, H, W, N, ksize, flags, variant, nullptr, nullptr, 0, nullptr, false, stream, splits, workspace);
 }
 
 extern "C" int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant) {

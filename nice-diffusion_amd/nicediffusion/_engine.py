@@ -95,6 +95,12 @@ def _bf16_epilogue_stats():
     return int(os.environ.get('ND_BF16_EPILOGUE_STATS', '1'))
 
 
+def _bf16_splitk():
+    """ND_BF16_SPLITK (default 1): bf16 convs on small maps (<= 8192 output pixels, >= 512 input channels) are also measured
+    split over K (nd_conv_bf16_splitk_nhwc, 2 and 4 splits) and run that way where it is faster; 0: never."""
+    return os.environ.get('ND_BF16_SPLITK', '1') == '1'
+
+
 def _fuse_gn_mode():
     """0: never fold GroupNorm into the consumer conv; 1 (default): fold the affine-only norms (attention); 2: also fold
     norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
@@ -175,6 +181,7 @@ class UNetPlan:
         self._gn_slots = 0
         self._gn_doubles = 0     # float64 words of GroupNorm partial statistics ([NI][blocks][32][2] per norm)
         self._cs_floats = 0     # fp32 words of partial output statistics (see conv(want_stats=True))
+        self._splitk_floats = 0  # fp32 words of the split-K workspace shared by the convs that use it
         self.taps = []          # (module name, number of ops emitted when its output is complete, Act): debug hook
         _load_tune_cache()
         n_tuned = len(_TUNED)
@@ -381,12 +388,19 @@ class UNetPlan:
         stats_ok = want_stats and _bf16_epilogue_stats() and ksize == 3 and out.bf16 and out.ld == N
         if stats_ok:
             key = key + ('stats',)
-        var, with_stats = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT, out if stats_ok else None)
+        var, mode = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT, out if stats_ok else None)
+        with_stats = mode == 'stats'
         wq = self._packed_bf16(weight, pad_c_to, self.lib.nd_conv_bf16_variant_layout(var))
         self.keep.append(wq)
         self.packed_floats += wq.numel() // 2
         head[W_SLOT] = wq.data_ptr()
-        if with_stats:
+        if isinstance(mode, tuple):
+            # too few output tiles to fill the chip: split over K into a shared fp32 workspace + a deterministic reduce
+            splits = mode[1]
+            self._splitk_floats = max(self._splitk_floats, splits * NI * H * W * N)
+            self._emit(self.lib.nd_conv_bf16_splitk_nhwc, head + [var, splits, ('splitk', 0)], label, flops=fl,
+                       variant=('bf16', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+        elif with_stats:
             # the conv's epilogue leaves the next GroupNorm's partial statistics behind (no pass over `out`)
             rows = self.lib.nd_conv_bf16_stats_rows(NI, H, W, N, var)
             assert rows > 0
@@ -405,17 +419,19 @@ class UNetPlan:
         return out
 
     def _pick_bf16(self, key, flops, head, gn, weight, pad_c_to, w_slot, stats_out=None):
-        """(tile variant, with_stats) for one bf16 conv launch: -1 (the library's cost model) for tiny launches or with
+        """(tile variant, mode) for one bf16 conv launch, mode = 'plain' | 'stats' | ('splitk', splits): -1 (the library's cost model) for tiny launches or with
         ND_AUTOTUNE=0, else measured like the fp32 path (best of two bursts of 6 launches per variant that fits), cached per
         shape.  ``stats_out`` (the output Act of a conv feeding a GroupNorm): the variants that can leave the norm's partial
         statistics behind are also measured doing so, and that form is taken when it beats the best plain variant plus the
         measured statistics pass over the output."""
         if not _autotune_enabled() or flops < 2e8:
-            return -1, False
+            return -1, 'plain'
         ck = (self.device.index,) + key
         if ck in _TUNED:
-            kind, v = _TUNED[ck]
-            return v, kind == 'bf16+stats'
+            c = _TUNED[ck]
+            if c[0] == 'bf16+splitk':
+                return c[1], ('splitk', c[2])
+            return c[1], ('stats' if c[0] == 'bf16+stats' else 'plain')
         stream = self._stream()
         fn = self.lib.nd_conv_bf16_nhwc
 
@@ -468,12 +484,17 @@ class UNetPlan:
                         if sbest_ms is None or t < sbest_ms:
                             sbest, sbest_ms = v, t
         choice = ('bf16', best)
-        if sbest >= 0:
+        cost = best_ms
+        pass_ms = 0.0
+        if stats_out is not None:
             o = stats_out
             nblk = self.lib.nd_groupnorm_stats_blocks(o.NI, o.H * o.W, o.C, self.dt)
             part = torch.empty(o.NI * nblk * GN_GROUPS * 2, dtype=torch.float64, device=self.device)
             pargs = [o.ptr, o.C, o.ld, None, 0, 0, None, 0, part.data_ptr(), o.NI, o.H * o.W, GN_GROUPS, self.dt]
             pass_ms = measure(self.lib.nd_groupnorm_stats_nhwc, pargs)
+            cost = best_ms + pass_ms
+        if sbest >= 0:
+            o = stats_out
             fold = torch.empty(o.NI * GN_GROUPS * 2, dtype=torch.float64, device=self.device)
             rows = self.lib.nd_conv_bf16_stats_rows(o.NI, o.H, o.W, o.C, sbest)
             fargs = [scratch.data_ptr(), o.C, rows, None, 0, 0, fold.data_ptr(), o.NI, GN_GROUPS]
@@ -481,10 +502,34 @@ class UNetPlan:
             if os.environ.get('ND_TUNE_VERBOSE', '0') == '1':
                 print('[tune] %s: plain v%d %.4f ms + pass %.4f | stats v%d %.4f ms + fold %.4f' %
                       (key[1:7], best, best_ms, pass_ms, sbest, sbest_ms, fold_ms), file=sys.stderr)
-            if sbest_ms + fold_ms < best_ms + pass_ms or _bf16_epilogue_stats() == 2:
-                choice = ('bf16+stats', sbest)
+            if sbest_ms + fold_ms < cost or _bf16_epilogue_stats() == 2:
+                choice, cost = ('bf16+stats', sbest), sbest_ms + fold_ms
+        # split over K: layers with few output tiles and a long contraction (8x8 / 16x16 maps)
+        NI_, H_, W_, N_, flags_ = head[14], head[15], head[16], head[17], head[19]
+        M_ = NI_ * H_ * W_
+        Cin = head[1] + head[4]
+        if _bf16_splitk() and _bf16_epilogue_stats() != 2 and M_ <= 8192 and Cin >= 512 and gn[0] is None and N_ % 4 == 0 and \
+                not (flags_ & (_hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X | _hip.CONV_OUT_F32)):
+            ws = torch.empty(4 * M_ * N_, dtype=torch.float32, device=self.device)
+            cands = [best] + [v for v in (19, 7, 5, 11) if v != best and v < self.lib.nd_conv_bf16_num_variants()]
+            for v in cands:
+                lay = self.lib.nd_conv_bf16_variant_layout(v)
+                h = list(head)
+                h[w_slot] = packed[lay].data_ptr()
+                for S in (2, 4):
+                    kargs = h + [v, S, ws.data_ptr()]
+                    if self.lib.nd_conv_bf16_splitk_nhwc(*kargs, stream) != 0:
+                        continue
+                    t = measure(self.lib.nd_conv_bf16_splitk_nhwc, kargs)
+                    if os.environ.get('ND_TUNE_VERBOSE', '0') == '1':
+                        print('[tune] %s: split-K v%d x%d %.4f ms (+ pass %.4f) vs %.4f' % (key[1:7], v, S, t, pass_ms, cost),
+                              file=sys.stderr)
+                    if t + pass_ms < cost:
+                        choice, cost = ('bf16+splitk', v, S), t + pass_ms
         _TUNED[ck] = choice
-        return choice[1], choice[0] == 'bf16+stats'
+        if choice[0] == 'bf16+splitk':
+            return choice[1], ('splitk', choice[2])
+        return choice[1], ('stats' if choice[0] == 'bf16+stats' else 'plain')
 
     def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
         """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct
@@ -682,7 +727,12 @@ class UNetPlan:
         self.ch_partials = torch.zeros(max(4, self._cs_floats), dtype=torch.float32, device=dev)
         cs_base = self.ch_partials.data_ptr()
 
+        self.splitk_ws = torch.empty(max(4, self._splitk_floats), dtype=torch.float32, device=dev)
+        sk_base = self.splitk_ws.data_ptr()
+
         def bind(a):
+            if isinstance(a, tuple) and a and a[0] == 'splitk':
+                return sk_base
             if isinstance(a, tuple) and a and a[0] == 'gnstats':
                 return base + a[1] * 8
             if isinstance(a, tuple) and a and a[0] == 'chpart':

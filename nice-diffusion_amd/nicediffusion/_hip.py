@@ -53,6 +53,8 @@ SIGNATURES = {
     'nd_conv3x3_bf16_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                    _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     'nd_conv_bf16_stats_rows': [_i, _i, _i, _i, _i],
+    'nd_conv_bf16_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                 _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_repack_conv_weight_bf16': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_f32_to_bf16_rows': [_vp, _i, _vp, _i, _i, _i64, _vp],
     'nd_attention_bf16_nhwc': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],

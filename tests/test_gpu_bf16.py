@@ -336,6 +336,67 @@ def test_bf16_forward_with_epilogue_statistics_matches_statistics_pass(monkeypat
     assert rms < 1e-2 and mx < 4e-2
 
 
+@pytest.mark.parametrize('B,C0,C1,N,H,W,ksize,opts', [
+    (4, 512, 0, 256, 8, 8, 3, 'residual'), (2, 320, 192, 128, 8, 8, 3, 'rowbias'), (3, 256, 128, 96, 16, 16, 1, 'residual'),
+    (2, 1024, 0, 64, 8, 8, 1, 'silu'), (1, 200, 56, 72, 8, 8, 3, '')])
+def test_conv_bf16_split_k(B, C0, C1, N, H, W, ksize, opts):
+    """nd_conv_bf16_splitk_nhwc (block rows over ranges of input-channel chunks, fp32 partials, ordered reduce with bias /
+    per-image bias / residual / SiLU) against the float64 statement of the op and against the one-pass kernel: the two differ
+    only by the association of the fp32 sums (<= 1 bf16 ulp after rounding); two-source inputs whose seam falls inside a
+    split, channel tails, repeated launches give the same bits."""
+    C = C0 + C1
+    xa = rnd(B, C0, H, W, seed=1)
+    xb = rnd(B, C1, H, W, seed=2) if C1 else None
+    w = rnd(N, C, ksize, ksize, seed=3, scale=0.03)
+    b, rb, res = rnd(N, seed=4), rnd(B, N, seed=5), rnd(B, N, H, W, seed=6)
+    x = q(xa) if not C1 else torch.cat([q(xa), q(xb)], 1)
+    ref = F.conv2d(x.double(), q(w).double(), b.double(), padding=ksize // 2)
+    if 'rowbias' in opts:
+        ref = ref + rb.double()[:, :, None, None]
+    if 'residual' in opts:
+        ref = ref + q(res).double()
+    if 'silu' in opts:
+        ref = F.silu(ref)
+    ref = ref.float()
+    xad, xbd = nhwc_bf(xa), (nhwc_bf(xb) if C1 else None)
+    bd, rbd, resd = b.to(DEV), rb.to(DEV), nhwc_bf(res)
+    wds = [pack_bf(w if ksize == 3 else w[:, :, 0, 0], lay) for lay in (0, 1)]
+    flags = _hip.CONV_SILU_OUT if 'silu' in opts else 0
+    head = [xad.data_ptr(), C0, C0, None if not C1 else xbd.data_ptr(), C1, C1, None, bd.data_ptr(),
+            rbd.data_ptr() if 'rowbias' in opts else None, N if 'rowbias' in opts else 0,
+            resd.data_ptr() if 'residual' in opts else None, N if 'residual' in opts else 0]
+    ran = 0
+    for v in range(lib().nd_conv_bf16_num_variants()):
+        head[6] = wds[lib().nd_conv_bf16_variant_layout(v)].data_ptr()
+        plain = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        if lib().nd_conv_bf16_nhwc(*head, plain.data_ptr(), N, B, H, W, N, ksize, flags, v, None, None, 0, st()) != 0:
+            continue
+        for S in (2, 3, 4):
+            ws = torch.full((S * B * H * W * N,), float('nan'), dtype=torch.float32, device=DEV)
+            out = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+            rc = lib().nd_conv_bf16_splitk_nhwc(*head, out.data_ptr(), N, B, H, W, N, ksize, flags, v, S, ws.data_ptr(), st())
+            if rc != 0:
+                assert 'split-K' in _hip.last_error(), _hip.last_error()
+                continue
+            ran += 1
+            got = from_nhwc(out, B, H, W, N)
+            assert torch.isfinite(got).all(), (v, S)
+            err = (got - ref).abs()
+            assert (err <= _tol_bf16(ref)).all(), (v, S, err.max().item())
+            d = (got - from_nhwc(plain, B, H, W, N)).abs()
+            assert (d <= 2.0 ** -7 * ref.abs() + 1e-3).all(), (v, S, d.max().item())
+            out2 = torch.empty_like(out)
+            _hip.check(lib().nd_conv_bf16_splitk_nhwc(*head, out2.data_ptr(), N, B, H, W, N, ksize, flags, v, S, ws.data_ptr(), st()))
+            assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), (v, S)
+    assert ran >= 4
+    # refused: fused GroupNorm is not an argument; upsampled reads and fp32 output are rejected
+    out = torch.empty(B * H * W * N, dtype=BF, device=DEV)
+    ws = torch.empty(2 * B * H * W * N, dtype=torch.float32, device=DEV)
+    head[6] = wds[0].data_ptr()
+    assert lib().nd_conv_bf16_splitk_nhwc(*head, out.data_ptr(), N, B, H, W, N, ksize, _hip.CONV_OUT_F32, 7, 2, ws.data_ptr(), st()) != 0
+    assert lib().nd_conv_bf16_splitk_nhwc(*head, out.data_ptr(), N, B, H, W, N, ksize, flags, -1, 2, ws.data_ptr(), st()) != 0
+
+
 def test_conv_bf16_long_k_full_size_layer():
     """A full-size layer of the 128x128 preset (two-source 512+256 -> 256 at 64x64, B=2): long contraction (K = 6912),
     every variant that fits gives the same result as the cost model's pick to within output rounding."""
