@@ -510,13 +510,14 @@ class UNetPlan:
         Cin = head[1] + head[4]
         if _bf16_splitk() and _bf16_epilogue_stats() != 2 and M_ <= 8192 and Cin >= 512 and gn[0] is None and N_ % 4 == 0 and \
                 not (flags_ & (_hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X | _hip.CONV_OUT_F32)):
-            ws = torch.empty(4 * M_ * N_, dtype=torch.float32, device=self.device)
+            splits = (2, 4)           # 8 splits on the 1024-pixel layers measured equal to 4
+            ws = torch.empty(splits[-1] * M_ * N_, dtype=torch.float32, device=self.device)
             cands = [best] + [v for v in (19, 7, 5, 11) if v != best and v < self.lib.nd_conv_bf16_num_variants()]
             for v in cands:
                 lay = self.lib.nd_conv_bf16_variant_layout(v)
                 h = list(head)
                 h[w_slot] = packed[lay].data_ptr()
-                for S in (2, 4):
+                for S in splits:
                     kargs = h + [v, S, ws.data_ptr()]
                     if self.lib.nd_conv_bf16_splitk_nhwc(*kargs, stream) != 0:
                         continue
