@@ -415,6 +415,30 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #if defined(ND_HABL_NOEPI)
     if (p.N > 0) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.out)[0] = acc[0][0][1]; return; }
 #endif
+#if defined(ND_HABL_EPICOAL)
+    // timing-only: the wave's output region written ONCE with ideally coalesced 16-byte stores (8 lanes = one pixel's 128
+    // bytes), wrong values -- what an LDS-staged epilogue could reach at most
+    if (p.N > 0 && !p.out_f32) {
+        constexpr int CPR = TN * 4;                      // 16-byte pieces per pixel row of the wave tile
+#pragma unroll
+        for (int it = 0; it < TM * TN * 2; ++it) {
+            const int idx = it * 64 + lane;
+            const int pl = idx / CPR, piece = idx - pl * CPR;
+            const int m = wm * TM * 32 + pl;
+            const int oy = oy0 + ((m >> p.twl) & (TH - 1)), ox = ox0 + (m & (TW - 1));
+            const int n = n0 + wn * TN * 32 + piece * 8;
+            const int r = it * 8;
+            f32x4 lo = {acc[0][0][r & 15], acc[TM - 1][0][(r + 1) & 15], acc[0][TN - 1][(r + 2) & 15], acc[TM - 1][TN - 1][(r + 3) & 15]};
+            lo += *reinterpret_cast<const f32x4*>(p.bias + (n & ~3));
+            union { bf16x8 h; f32x4 f; } o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.h[e] = (__bf16)(lo[e & 3] + (float)e);
+            if (oy < p.H && ox < p.W && n + 7 < p.N)
+                *reinterpret_cast<f32x4*>(static_cast<__bf16*>(p.out) + (size_t)((img0 * p.H + oy) * p.W + ox) * p.ldo + n) = o.f;
+        }
+        return;
+    }
+#endif
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
