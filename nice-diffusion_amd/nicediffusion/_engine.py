@@ -97,8 +97,9 @@ def _bf16_epilogue_stats():
 
 def _bf16_splitk():
     """ND_BF16_SPLITK (default 1): bf16 convs on small maps (<= 8192 output pixels, >= 512 input channels) are also measured
-    split over K (nd_conv_bf16_splitk_nhwc, 2 and 4 splits) and run that way where it is faster; 0: never."""
-    return os.environ.get('ND_BF16_SPLITK', '1') == '1'
+    split over K (nd_conv_bf16_splitk_nhwc, 2 and 4 splits) and run that way where it is faster; 0: never; 2: wherever a
+    split form exists (tests)."""
+    return int(os.environ.get('ND_BF16_SPLITK', '1'))
 
 
 def _fuse_gn_mode():
@@ -525,7 +526,7 @@ class UNetPlan:
                     if os.environ.get('ND_TUNE_VERBOSE', '0') == '1':
                         print('[tune] %s: split-K v%d x%d %.4f ms (+ pass %.4f) vs %.4f' % (key[1:7], v, S, t, pass_ms, cost),
                               file=sys.stderr)
-                    if t + pass_ms < cost:
+                    if t + pass_ms < cost or (_bf16_splitk() == 2 and choice[0] != 'bf16+splitk'):
                         choice, cost = ('bf16+splitk', v, S), t + pass_ms
         _TUNED[ck] = choice
         if choice[0] == 'bf16+splitk':

@@ -397,6 +397,31 @@ def test_conv_bf16_split_k(B, C0, C1, N, H, W, ksize, opts):
     assert lib().nd_conv_bf16_splitk_nhwc(*head, out.data_ptr(), N, B, H, W, N, ksize, flags, -1, 2, ws.data_ptr(), st()) != 0
 
 
+def test_bf16_forward_with_split_k_matches_one_pass(monkeypatch):
+    """ND_BF16_SPLITK=2 (split-K wherever a split form exists) against ND_BF16_SPLITK=0 on a model with 512 channels at
+    8x8: the forwards agree to within a few bf16 roundings and the split form is actually in the plan."""
+    from nicediffusion import _engine
+    cfg = dict(TINY_CFGS['adagn_updown'], resolution=16, model_channels=256, attention_resolutions=(8,), num_head_channels=64)
+    B = 8
+    x = rnd(B, 3, 16, 16, seed=3).to(DEV)
+    t = torch.tensor([5, 100, 300, 999, 0, 1, 2, 3], device=DEV)
+    y = torch.arange(B, device=DEV) % 10
+    outs = {}
+    for mode in ('2', '0'):
+        monkeypatch.setenv('ND_BF16_SPLITK', mode)
+        _engine._TUNED.clear()
+        m = build(cfg)
+        outs[mode] = m(x, t, y=y).float().cpu()
+        plan = next(iter(m._plans.values()))
+        used = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_conv_bf16_splitk_nhwc')
+        assert (used > 0) == (mode == '2'), (mode, used)
+    _engine._TUNED.clear()
+    assert torch.isfinite(outs['2']).all()
+    rms, mx = _errs(outs['2'], outs['0'])
+    print('split-K vs one pass: rms %.2e max %.2e' % (rms, mx))
+    assert rms < 1e-2 and mx < 4e-2
+
+
 def test_conv_bf16_long_k_full_size_layer():
     """A full-size layer of the 128x128 preset (two-source 512+256 -> 256 at 64x64, B=2): long contraction (K = 6912),
     every variant that fits gives the same result as the cost model's pick to within output rounding."""
