@@ -128,6 +128,11 @@ __device__ __forceinline__ void sum8_over_32_lanes(f32x4& a, f32x4& b) {
 struct ConvArgs;
 // conv_winow_kernel (nd_conv_winograd_wave.hip), launched by nd_conv3x3_winograd_nhwc's variant 11
 int launch_winow(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
+// conv_wino4_kernel (nd_conv_winograd_quad.hip), launched by nd_conv3x3_winograd_nhwc's variant 12: 4 waves, 128 px x 64 ch,
+// two blocks per CU; its halo buffers are filled by kWino4HaloRounds LDS-DMA rounds of 4 waves x 64 lanes x 16 bytes
+constexpr int kWino4HaloRounds = 7;
+constexpr int kWino4HaloPixels = kWino4HaloRounds * 4 * 64 / 8;      // 224 >= the 208 halo pixels the host admits
+int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
 // gemm_f32_kernel (nd_gemm_f32.hip), launched by nd_conv_nhwc's variant 13
 int launch_gemm_f32(const ConvArgs& a, int grid, hipStream_t s);
 

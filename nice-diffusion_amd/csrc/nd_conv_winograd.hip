@@ -1402,8 +1402,10 @@ static const int kWinoCfg[][4] = {{2, 1, 0, 2}, {1, 1, 0, 2}, {1, 1, 1, 2}, {1, 
                                  // persistent position-split form (conv_wino16p_kernel); coded as WN = 6
                                  {1, 1, 0, 6},
                                  // whole transform per wave (conv_winow_kernel): 4 waves, 256 px x 64 ch; coded as WN = 7
-                                 {2, 1, 0, 7}};
-static constexpr int kNumWino = 12;
+                                 {2, 1, 0, 7},
+                                 // row per wave, two n tiles per wave, two blocks per CU (conv_wino4_kernel): 4 waves, 128 px x 64 ch; coded as WN = 8
+                                 {1, 1, 0, 8}};
+static constexpr int kNumWino = 13;
 static constexpr int kStatsVariant = 8;        // conv_wino16_kernel: the one whose epilogue can emit output statistics
 
 template <int TMW, int NSUB, bool APF, int WNT>
@@ -1434,7 +1436,8 @@ extern "C" const char* nd_conv_winograd_variant_name(int variant) {
                                   "nd::conv_wino_kernel<1, 2, false, 2>", "nd::conv_wino_kernel<1, 1, false, 1>",
                                   "nd::conv_wino_kernel<1, 2, false, 3>", "nd::conv_wino_kernel<1, 1, false, 3>",
                                   "nd::conv_wino16_kernel<1>",            "nd::conv_wino16g_kernel",
-                                  "nd::conv_wino16p_kernel",              "nd::conv_winow_kernel"};
+                                  "nd::conv_wino16p_kernel",              "nd::conv_winow_kernel",
+                                  "nd::conv_wino4_kernel"};
     static_assert(sizeof(names) / sizeof(names[0]) == kNumWino, "one name per variant");
     return (variant < 0 || variant >= kNumWino) ? "" : names[variant];
 }
@@ -1443,7 +1446,7 @@ extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int*
     if (variant < 0 || variant >= kNumWino) return ND_E_ARG;
     if (bm) *bm = kWinoCfg[variant][0] * 128;
     const bool split = kWinoCfg[variant][3] >= 4 && kWinoCfg[variant][3] <= 6;
-    const bool wave16 = kWinoCfg[variant][3] == 7;
+    const bool wave16 = kWinoCfg[variant][3] >= 7;       // 7: whole transform per wave, 8: row per wave x 2 n tiles; both 256 threads, 64 channels
     if (bn) *bn = wave16 ? 64 : (split ? 96 : kWinoCfg[variant][3] * 32);
     if (threads) *threads = wave16 ? 256 : (split ? 1024 : kWinoCfg[variant][3] * 256);
     if (nsub) *nsub = kWinoCfg[variant][1];
@@ -1510,14 +1513,16 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
+    const bool quad = kWinoCfg[variant][3] == 8;
     const bool wave16 = kWinoCfg[variant][3] == 7;
-    const bool split = kWinoCfg[variant][3] >= 4 && !wave16;
+    const bool split = kWinoCfg[variant][3] >= 4 && !wave16 && !quad;
     const bool dma = kWinoCfg[variant][3] == 5;
     const bool persistent = kWinoCfg[variant][3] == 6;
-    const int WM = kWinoCfg[variant][0], WN = wave16 ? 2 : (split ? 3 : kWinoCfg[variant][3]);
+    const int WM = kWinoCfg[variant][0], WN = (wave16 || quad) ? 2 : (split ? 3 : kWinoCfg[variant][3]);
     const int nsub = kWinoCfg[variant][1];
-    const int nt = wave16 ? 256 : (split ? 1024 : 256 * WN);
-    const int hpmax = wave16 ? 416 : ((WM == 2) ? 384 : ((WN == 3) ? 208 : 192));   // = the kernel's HPMAX
+    const int nt = (wave16 || quad) ? 256 : (split ? 1024 : 256 * WN);
+    const int hpmax = wave16 ? 416 : (quad ? 208 : ((WM == 2) ? 384 : ((WN == 3) ? 208 : 192)));   // = the kernel's HPMAX
+    static_assert(kWino4HaloPixels >= 208, "conv_wino4_kernel's DMA rounds cover the halo the host admits");
     TilePlan best{};
     const bool found = wino_tiles(WM, nsub, hpmax, NI, H, W, &best);
     if (!found) return fail_arg(fn, "no tiling fits this shape");
@@ -1544,7 +1549,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         ND_REQUIRE(gnB != nullptr && ld_gn >= C0 + C1 && (ld_gn & 3) == 0 && aligned16(gnA) && aligned16(gnB), fn,
                    "fused GroupNorm: bad coefficient arrays");
         ND_REQUIRE(best.nibl == 0, fn, "fused GroupNorm needs one image per block (H*W >= pixel tile)");
-        ND_REQUIRE(!split && !wave16, fn, "the position-split and whole-transform-per-wave variants do not fold GroupNorm into the loader");
+        ND_REQUIRE(!split && !wave16 && !quad, fn, "the position-split, whole-transform-per-wave and two-blocks-per-CU variants do not fold GroupNorm into the loader");
     }
     const int grid = a.mt * a.nt;
     size_t lds = (size_t)2 * best.hp * 128 * nsub;
@@ -1552,6 +1557,15 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (split && lds < (size_t)128 * 1024) lds = (size_t)128 * 1024;    // two 64 KiB exchange buffers
     if (wave16) lds = (size_t)65536 + (size_t)best.hp * 128 + 64;       // halo buffer 0 | buffer 1 at 64 KiB | a spare slot (no epilogue exchange)
     if (dma) lds = (size_t)160 * 1024;
+    if (quad) {
+        // conv_wino4_kernel addresses its input through buffer descriptors: 32-bit byte offsets with the range check as
+        // zero padding, whole 32-channel chunks on either side of the concatenation seam
+        ND_REQUIRE(((C0 + C1) & 31) == 0 && (C1 == 0 || (C0 & 31) == 0), fn, "the two-blocks-per-CU variant needs whole 32-channel chunks");
+        ND_REQUIRE((long)NI * (H >> up) * (W >> up) * ldx0 * 4 < (1L << 31) && (C1 == 0 || (long)NI * (H >> up) * (W >> up) * ldx1 * 4 < (1L << 31)), fn,
+                   "the two-blocks-per-CU variant needs input tensors of less than 2 GiB");
+        lds = (size_t)64 * 1024;          // two 28 KiB halo buffers; the epilogue exchange takes all 64 KiB (two blocks per CU)
+        if (const char* e = getenv("ND_W4_LDS_KB")) lds = (size_t)atoi(e) * 1024;      // diagnostics: > 80 forces one block per CU
+    }
     if (persistent) {
         ND_REQUIRE((a.NC32 & 1) == 0, fn, "the persistent form needs an even number of 32-channel chunks");
         lds = (size_t)best.hp * 128 + (size_t)128 * 1024;      // halo buffer 0 | exchange buffers (over halo buffer 1)
@@ -1572,6 +1586,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
         case 11: return launch_winow(a, grid, lds, s);
+        case 12: return launch_wino4(a, grid, lds, s);
         case 10: {
             static bool attr_set[kMaxDevices] = {};
             if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino16p_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;

@@ -1,0 +1,498 @@
+// K5, Winograd F(2x2,3x3), row-per-wave form with two n tiles per wave and TWO BLOCKS PER CU (variant 12 of
+// nd_conv3x3_winograd_nhwc; reference op: nicediffusion/model.py:173-177,194,209 -- the ResidualBlock 3x3 convs).
+//
+// Why this shape.  conv_wino16_kernel (16 waves, one transform position per wave) owns its CU: the block's prologue
+// (index arithmetic by 16 waves, first halo chunk from HBM), its LDS-exchange epilogue and the dispatch gap between
+// two blocks run with the matrix pipes idle -- 14 % of a 6-chunk 64x64 layer, and its 128-register budget leaves the
+// weight stream one k-step of read-ahead.  Here a block is 4 waves (one per SIMD) at <= 256 registers, so TWO blocks
+// share a CU and the SIMD's matrix pipe is time-shared by two waves of DIFFERENT blocks: one block's prologue /
+// epilogue / barrier waits sit under the other block's MFMAs (arbitration is by age, so the two blocks fall out of
+// step by themselves).
+//   * wave xi owns row xi of the 4x4 transform (positions (xi, 0..3)) for 32 tiles x 2 n tiles: 8 accumulators = 128
+//     registers; one transformed A fragment feeds 2 x 4 MFMAs, one weight fragment 4;
+//   * the row part of the output transform (sum over nu) is register arithmetic; only the sum over xi goes through
+//     LDS (half the exchange of the position-split form), all of it in ONE round with one barrier;
+//   * halo chunks arrive by LDS-DMA (global_load_lds_dwordx4, swizzle on the per-lane SOURCE address, zero padding
+//     from a zero block): no staging registers, no ds_write; chunk c + 2 is issued as soon as chunk c's buffer has
+//     been read for the last time, one full chunk (8192 own matrix cycles) before it is needed;
+//   * software pipeline inside the wave: the raw patch entries of k-step s + 1 are read and transformed under the
+//     MFMAs of k-step s, the weight fragments of a position are re-loaded (same registers) right behind the MFMAs
+//     that consumed them -- three positions = 1536 own matrix cycles of read-ahead; the barrier per chunk sits after
+//     k-step 2 so that the prefetch for the next chunk's first k-step never waits for it.
+// Weight layout, halo image, k order and the association of every sum are those of conv_wino_kernel /
+// conv_wino16_kernel: the kernels give the same bits (tests/test_gpu_kernels.py).
+#include "nd_conv_common.h"
+
+namespace nd {
+
+__global__ void __launch_bounds__(256, 2)
+    conv_wino4_kernel(const ConvArgs p) {
+    constexpr int BN = 64;
+    constexpr int FRAGS = 64;
+    constexpr int NDMA = kWino4HaloRounds;     // halo DMA rounds per chunk: 7 x 4 waves x 64 lanes x 16 B = 28 KiB >= 208 px x 128 B
+    constexpr int HBUF = 8192;                 // floats between the two halo buffers: 32 KiB, ONE address bit (a buffer holds NDMA KiB x 4 = 28 KiB)
+    static_assert(NDMA * 4 * 256 <= HBUF, "a halo buffer fits its 32 KiB slot");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // 2 halo buffers at 0 and 32 KiB; the epilogue exchange uses 64 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#if defined(ND_W4_DIAG)
+    // diagnostic build only (tools/wino4_timeline.py): stamps go to the buffer passed as `rowbias`, which is then ignored
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_c1 = 0, dg_c2 = 0;
+#endif
+#if !defined(ND_W4_NOPRIO)
+    // prologue and epilogue are vector / memory instruction streams without MFMAs; the other block of this CU is in its
+    // MFMA loop meanwhile and, being older, would win every issue slot: run these two phases at raised priority
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave = row of the 4x4 transform (kept in an SGPR)
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int tx = mblk % p.tiles_x;
+    const int tmp = mblk / p.tiles_x;
+    const int ty = tmp % p.tiles_y;
+    const int ig = tmp / p.tiles_y;
+
+    const int TH = 1 << p.thl, TW = 1 << p.twl;
+    const int HH = TH + 2, HW = TW + 2;
+    const int HPI = HH * HW;
+    const int HP = HPI << p.nibl;
+    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
+    const int n0 = nblk * BN;
+
+    // LDS image of the halo (the one of conv_wino_kernel, 128-byte pixel rows): 16-byte unit U = (hp >> 1) * 16 +
+    // ((((hp & 1) << 3) | slot) ^ key), key = ((hy >> 1) & 3) << 2 | ((hx >> 1) & 3)
+    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {
+        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
+        return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
+    };
+
+    // ---- halo DMA descriptors.  Round k of this wave fills units (k * 4 + xi) * 64 + lane; un-swizzling the unit gives the
+    //      pixel and the channel slot it holds.  What is kept per round is the lane's BYTE OFFSET into source 0 and into
+    //      source 1 (the skip tensor of a concatenation), so that a DMA in the main loop costs no vector instruction at
+    //      all: buffer_load ... lds with the chunk's channel offset in the scalar offset.  (On these fp32 kernels every
+    //      vector instruction issued on a SIMD -- by either of its two waves -- takes its 4 cycles away from the matrix
+    //      pipe: tools/wino4_timeline.py measured 76 cycles per MFMA for a stream of MFMAs with 3 VALU each, and the
+    //      per-lane address arithmetic of the first version, 28 VALU per DMA, cost 10 % of the kernel.)  Zero padding is
+    //      the buffer's range check: lanes outside the image carry an offset past num_records and the DMA writes zeros.
+    const int Ctot = p.C0 + p.C1;
+    constexpr unsigned kOOB = 0x80000000u;          // the host admits tensors of < 2 GiB
+    const unsigned mHPI = 65536u / (unsigned)HPI + 1u, mHW = 65536u / (unsigned)HW + 1u;       // n / d = (n * m) >> 16 for n < 65536 / d
+    unsigned vo0[NDMA], vo1[NDMA];
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+        const int U = (k * 4 + xi) * 64 + lane;
+        const int hp0 = (U >> 4) * 2;
+        const int li = (int)(((unsigned)hp0 * mHPI) >> 16);
+        const int rem = hp0 - li * HPI;
+        const int hy = (int)(((unsigned)rem * mHW) >> 16);
+        const int hx0 = rem - hy * HW;              // even; the pair (hx0, hx0 + 1) shares the swizzle key
+        const int key = (((hy >> 1) & 3) << 2) | ((hx0 >> 1) & 3);
+        const int t = (U & 15) ^ key;
+        const int hx = hx0 + (t >> 3);
+        const int img = img0 + li;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        const bool ok = hp0 < HP && img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const unsigned pix = (unsigned)((img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up));
+        const unsigned sl16 = (unsigned)(t & 7) << 4;
+        vo0[k] = ok ? (pix * (unsigned)p.ldx0 * 4u + sl16) : kOOB;
+        vo1[k] = ok ? (pix * (unsigned)p.ldx1 * 4u + sl16) : kOOB;
+    }
+    const unsigned npix = (unsigned)(p.NI * p.Hs * p.Ws);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x0), 0, (int)(npix * (unsigned)p.ldx0 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, (int)(npix * (unsigned)p.ldx1 * 4u), 0x00020000);
+    // One DMA round of chunk ch (the host requires whole 32-channel chunks on either side of the concatenation seam).
+    // A round is ALWAYS issued -- rounds past the halo carry kOOB in every lane, chunks past the last one re-fetch the last
+    // chunk into a buffer nobody reads -- so that the number of VMEM operations per chunk is a constant the hand-counted
+    // waits can rely on.
+    auto halo_issue = [&](int k, int ch, int buf) {
+#if !defined(ND_WABL_NOHALO)
+        const int che = ch < p.NC32 - 1 ? ch : p.NC32 - 1;
+        const int c0 = che * 32;
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + (k * 4 + xi) * 256);
+        if (c0 < p.C0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)vo0[k], c0 * 4, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, (int)vo1[k], (c0 - p.C0) * 4, 0, 0);
+#endif
+    };
+
+    // (B^T d)[xi][j] = d[ra][j] + sgn * d[rb][j]:  xi=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
+    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
+    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
+    const float sgn = (xi == 1) ? 1.f : -1.f;
+
+    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
+    int off_a[4], off_b[4];          // LDS BYTE offsets (k-step 0) of patch rows ra / rb, columns 0..3, of this lane's tile
+    {
+        const int t = l31;
+        const int t_li = t >> (thl2 + twl2);
+        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
+        const int t_x = t & ((1 << twl2) - 1);
+        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            off_a[j] = lds_off(base + ra * HW + j, 2 * t_y + ra, 2 * t_x + j, lh) << 2;
+            off_b[j] = lds_off(base + rb * HW + j, 2 * t_y + rb, 2 * t_x + j, lh) << 2;
+        }
+    }
+
+    // weight fragments: positions 4 * xi .. 4 * xi + 3 (contiguous 4 KiB) of n tiles ntile0, ntile0 + 1 (N tail: clamped,
+    // results dropped in the epilogue)
+    const int ntile0 = nblk * 2;
+    const int nt1 = (ntile0 + 1 > p.NT32 - 1) ? (p.NT32 - 1) : (ntile0 + 1);
+    const int noff1 = (nt1 - ntile0) * (FRAGS * 256);
+    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nu][n][e] = 0.f;
+
+    // ---- operand streams, all issued as inline ISA with hand-counted waits.  Why not leave it to hipcc: (1) every LDS read
+    //      it can see is ordered behind ALL pending LDS-DMA (it cannot tell the two halo buffers apart: vmcnt(0) in front of
+    //      each patch read); (2) with LDS-DMA and register loads pending together it gives up counting and waits vmcnt(0)
+    //      for every weight fragment.  vmcnt retires in issue order, so the program order of the VMEM operations IS the
+    //      contract: per k-step and position nu the two fragment loads L(nu) behind the position's MFMAs, and in k-step 3
+    //      of every chunk the 7 halo DMAs of chunk + 2, kDmaInPos[nu] of them in front of L(nu).
+    //      The main loop is written as 32 MFMA 'slots' per k-step; every slot carries at most a handful of other
+    //      instructions (sched_barrier pins the order), so that ONE wave keeps its SIMD's matrix pipe full when the block
+    //      that shares the CU is in its prologue or epilogue (measured with tools/wino4_timeline.py: before this, a wave
+    //      alone reached 0.63 of the pipe and the halo address arithmetic alone cost 16 %).
+    constexpr int kDmaInPos[4] = {0, 2, 3, 2};
+    static_assert(kDmaInPos[0] + kDmaInPos[1] + kDmaInPos[2] + kDmaInPos[3] == NDMA, "one chunk = NDMA rounds");
+    // VMEM operations younger than L(nu) of the previous k-step when position nu of k-step st starts
+    auto younger = [&](int st, int nu) -> int {
+        int y = 2 * (3 - nu) + 2 * nu;                                      // fragment loads of positions > nu (previous k-step), < nu (this one)
+        if (st == 0) for (int m = nu + 1; m < 4; ++m) y += kDmaInPos[m];    // DMAs of the previous k-step 3 behind L(nu)
+        if (st == 3) for (int m = 0; m < nu; ++m) y += kDmaInPos[m];        // DMAs of this k-step 3 so far
+        return y;
+    };
+    f32x4 bfr[4][2];      // [nu][n tile]: re-loaded in place, one position at a time
+    const int voff = lane * 16;                                          // byte offset of this lane inside a 1 KiB fragment
+    const float* bw0 = p.w + ((size_t)ntile0 * FRAGS + 4 * xi) * 256;      // wave-uniform: SGPR base + VGPR lane offset
+    const float* bw1 = bw0 + noff1;
+    auto ldfrag = [&](f32x4& d, const float* sbase, int nu) {
+#if !defined(ND_WABL_NOB)
+        switch (nu) {
+            case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase)); break;
+            case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(d) : "v"(voff), "s"(sbase)); break;
+            case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(d) : "v"(voff), "s"(sbase)); break;
+            default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(d) : "v"(voff), "s"(sbase)); break;
+        }
+#else
+        asm volatile("" :: "s"(sbase));
+#endif
+    };
+    auto load_b_pos = [&](int nu, size_t foff) {          // foff: float offset of the k-step's fragment block
+#if defined(ND_WABL_BHIT)
+        foff = 0;             // timing only: the same fragments every k-step (cache hits)
+#endif
+        ldfrag(bfr[nu][0], bw0 + foff, nu);
+        ldfrag(bfr[nu][1], bw1 + foff, nu);
+    };
+    // wait until at most n younger VMEM operations are in flight; the fragments are tied to the wait so that no MFMA moves above it
+    auto wait_vm = [&](f32x4& d0, f32x4& d1, int n) {
+#if !defined(ND_WABL_NOB)
+#define ND_W4CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(d0), "+v"(d1)); break;
+        switch (n) {
+            ND_W4CASE(6) ND_W4CASE(7) ND_W4CASE(8) ND_W4CASE(9) ND_W4CASE(10) ND_W4CASE(11) ND_W4CASE(12) ND_W4CASE(13) ND_W4CASE(14)
+            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0), "+v"(d1)); break;
+        }
+#undef ND_W4CASE
+#endif
+    };
+    f32x4 v[4];           // transformed A fragments of the current k-step
+    auto MF = [&](int nu, int m) {          // MFMA slot m (0..7) of position nu
+#if defined(ND_W4_CHAIN4)
+        const int n = m >> 2, j = m & 3;    // four dependent MFMAs per accumulator in a row
+#else
+        const int n = m & 1, j = m >> 1;    // the two n tiles alternate: an accumulator is re-used every other MFMA
+#endif
+        acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[nu][n][j], v[nu][j], acc[nu][n], 0, 0, 0);
+    };
+    auto rd = [&](int hbase, int off, int kx) -> f32x4 {
+        f32x4 d;
+#if !defined(ND_WABL_NOA)
+        const int addr = off ^ (kx | hbase);          // buffer and k-step are bits of one scalar: one v_xor per read
+        asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
+#else
+        d = f32x4{(float)(off ^ kx), 1.f, 2.f, 3.f};
+#endif
+        return d;
+    };
+    // LDS reads return in order: wait until at most n younger ones are in flight (a pending scalar load only makes this stricter)
+    auto rd_wait = [&](f32x4& a, f32x4& b, int n) {
+#if !defined(ND_WABL_NOA)
+        switch (n) {
+            case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b)); break;
+            case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
+            case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
+            default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
+        }
+#endif
+    };
+#define ND_SB __builtin_amdgcn_sched_barrier(0)
+
+    const int nchunks = p.NC32;
+    // ---- prologue: chunk 0, then a 'virtual k-step 3' that issues the weights of k-step 0 and chunk 1 in the loop's order
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) halo_issue(k, 0, 0);
+    {
+        int k = 0;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+#pragma unroll
+            for (int i = 0; i < kDmaInPos[nu]; ++i, ++k) halo_issue(k, 1, 1);
+            load_b_pos(nu, 0);
+        }
+    }
+    // chunk 0 has landed when only the 8 fragment loads and chunk 1 are in flight
+#if !defined(ND_WABL_NOHALO)
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+    {
+        f32x4 a0 = rd(0, off_a[0], 0), b0 = rd(0, off_b[0], 0), a1 = rd(0, off_a[1], 0), b1 = rd(0, off_b[1], 0);
+        f32x4 a2 = rd(0, off_a[2], 0), b2 = rd(0, off_b[2], 0), a3 = rd(0, off_a[3], 0), b3 = rd(0, off_b[3], 0);
+        rd_wait(a0, b0, 0);
+        rd_wait(a1, b1, 0);
+        rd_wait(a2, b2, 0);
+        rd_wait(a3, b3, 0);
+        const f32x4 t0 = a0 + sgn * b0, t1 = a1 + sgn * b1, t2 = a2 + sgn * b2, t3 = a3 + sgn * b3;
+        v[0] = t0 - t2;
+        v[1] = t1 + t2;
+        v[2] = t2 - t1;
+        v[3] = t1 - t3;
+    }
+#if !defined(ND_W4_NOPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(ND_W4_DIAG)
+    dg_t1 = __builtin_amdgcn_s_memrealtime();
+    dg_c1 = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int hb = (ch & 1) * (HBUF * 4), hn = ((ch + 1) & 1) * (HBUF * 4);      // byte offsets of this / the next chunk's halo buffer
+        const size_t fq = (size_t)ch * c32_stride;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            // operands of the NEXT k-step: weights one k-step on (the stream ends in a zero block), patch entries from this
+            // chunk's buffer or -- for the last k-step -- from the next chunk's, which the barrier after k-step 2 released
+            const size_t fn = (st < 3) ? (fq + (st + 1) * (16 * 256)) : (fq + c32_stride);
+            const int an = (st < 3) ? hb : hn;
+            int kxn = ((st + 1) & 3) << 5;          // bytes
+            asm volatile("" : "+s"(kxn));          // keep the per-step addresses from being hoisted into registers
+            const bool dma = (st == 3);
+            const int dbuf = ch & 1;               // behind the barrier of k-step 2 this chunk's buffer is free for chunk ch + 2
+            f32x4 a0, b0, a1, b1, a2, b2, a3, b3, tr[4];
+            // ---- position 0: the raw patch entries of the next k-step are requested, one read per MFMA
+            wait_vm(bfr[0][0], bfr[0][1], younger(st, 0));
+            MF(0, 0); a0 = rd(an, off_a[0], kxn); ND_SB;
+            MF(0, 1); b0 = rd(an, off_b[0], kxn); ND_SB;
+            MF(0, 2); a1 = rd(an, off_a[1], kxn); ND_SB;
+            MF(0, 3); b1 = rd(an, off_b[1], kxn); ND_SB;
+            MF(0, 4); a2 = rd(an, off_a[2], kxn); ND_SB;
+            MF(0, 5); b2 = rd(an, off_b[2], kxn); ND_SB;
+            MF(0, 6); a3 = rd(an, off_a[3], kxn); ND_SB;
+            MF(0, 7); b3 = rd(an, off_b[3], kxn); ND_SB;
+            load_b_pos(0, fn); ND_SB;
+            // ---- position 1: row transform of the next patch as the reads return; k-step 3: DMA rounds 0, 1
+            wait_vm(bfr[1][0], bfr[1][1], younger(st, 1));
+            MF(1, 0); rd_wait(a0, b0, 6); tr[0] = a0 + sgn * b0; ND_SB;
+            MF(1, 1); rd_wait(a1, b1, 4); tr[1] = a1 + sgn * b1; ND_SB;
+            MF(1, 2); rd_wait(a2, b2, 2); tr[2] = a2 + sgn * b2; ND_SB;
+            MF(1, 3); rd_wait(a3, b3, 0); tr[3] = a3 + sgn * b3; ND_SB;
+            MF(1, 4); ND_SB;
+            MF(1, 5); if (dma) halo_issue(0, ch + 2, dbuf); ND_SB;
+            MF(1, 6); ND_SB;
+            MF(1, 7); if (dma) halo_issue(1, ch + 2, dbuf); ND_SB;
+            load_b_pos(1, fn); ND_SB;
+            // ---- position 2: v[0], v[1] of the next k-step replace the ones positions 0, 1 have consumed; DMA rounds 2, 3, 4
+            wait_vm(bfr[2][0], bfr[2][1], younger(st, 2));
+            MF(2, 0); v[0] = tr[0] - tr[2]; ND_SB;
+            MF(2, 1); v[1] = tr[1] + tr[2]; ND_SB;
+            MF(2, 2); ND_SB;
+            MF(2, 3); if (dma) halo_issue(2, ch + 2, dbuf); ND_SB;
+            MF(2, 4); ND_SB;
+            MF(2, 5); if (dma) halo_issue(3, ch + 2, dbuf); ND_SB;
+            MF(2, 6); ND_SB;
+            MF(2, 7); if (dma) halo_issue(4, ch + 2, dbuf); ND_SB;
+            load_b_pos(2, fn); ND_SB;
+            // ---- position 3: v[2]; DMA rounds 5, 6; v[3] behind the last MFMA that reads the old one
+            wait_vm(bfr[3][0], bfr[3][1], younger(st, 3));
+            MF(3, 0); v[2] = tr[2] - tr[1]; ND_SB;
+            MF(3, 1); ND_SB;
+            MF(3, 2); if (dma) halo_issue(5, ch + 2, dbuf); ND_SB;
+            MF(3, 3); ND_SB;
+            MF(3, 4); if (dma) halo_issue(6, ch + 2, dbuf); ND_SB;
+            MF(3, 5); ND_SB;
+            MF(3, 6); ND_SB;
+            MF(3, 7); v[3] = tr[1] - tr[3]; ND_SB;
+            load_b_pos(3, fn); ND_SB;
+            if (st == 2) {
+                // every read of this chunk's buffer has returned (k-step 3's were consumed above); chunk ch + 1 (issued a whole
+                // chunk ago) has landed once only this k-step's 8 fragment loads are in flight.  Behind the barrier the buffer
+                // of chunk ch is free for chunk ch + 2 (k-step 3's DMA slots).
+#if !defined(ND_WABL_NOBARRIER)
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+        }
+    }
+#undef ND_SB
+
+#if defined(ND_W4_DIAG)
+    dg_t2 = __builtin_amdgcn_s_memrealtime();
+    dg_c2 = __builtin_amdgcn_s_memtime();
+#endif
+#if !defined(ND_W4_NOPRIO)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#if defined(ND_WABL_NOEPI)
+    if (acc[0][1][1] + acc[1][0][2] + acc[2][1][5] + acc[3][0][11] == 77.125f) p.out[1] = 1.f;
+    if (acc[0][0][0] == 123.456f && acc[1][1][3] == 1.5f && acc[2][0][7] == 2.5f && acc[3][1][9] == 3.5f) p.out[0] = 1.f;
+    return;
+#endif
+    // ---- epilogue.  Accumulators are M^T (row = channel, col = tile): register group g4 of a lane = 4 consecutive
+    //      channels of its tile.  r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]) is formed in registers
+    //      and exchanged through LDS as ex[n][xi][b][g4][lane][4] (64 KiB, one round); wave w then finishes register
+    //      group w of both n tiles for all four xi: Y[a][b] = sum_xi At[a][xi] r_xi[b] -> 2x2 pixels x 4 channels per lane.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // run-ahead weight loads / patch reads have landed
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the halo buffers
+    float* ex = smem;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 r0, r1;
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int e = 4 * g4 + ee;
+                r0[ee] = acc[0][n][e] + acc[1][n][e] + acc[2][n][e];
+                r1[ee] = acc[1][n][e] - acc[2][n][e] - acc[3][n][e];
+            }
+            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 0) * 4 + g4) * 64 + lane) * 4) = r0;
+            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 1) * 4 + g4) * 64 + lane) * 4) = r1;
+        }
+    }
+    const int te = l31;
+    const int li = te >> (thl2 + twl2);
+    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
+    const int txx = te & ((1 << twl2) - 1);
+    const int img = img0 + li;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int nb = n0 + n * 32 + 8 * xi + 4 * lh;          // first of this lane's 4 output channels
+        f32x4 rr[4][2];
+#pragma unroll
+        for (int x2 = 0; x2 < 4; ++x2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+                rr[x2][b2] = *reinterpret_cast<const f32x4*>(ex + ((((n * 4 + x2) * 2 + b2) * 4 + xi) * 64 + lane) * 4);
+        if (nb < p.N && img < p.NI) {
+            const bool vec = p.vec_ok && (nb + 3 < p.N);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (vec) bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (nb + c < p.N) bv[c] = p.bias[nb + c];
+                }
+            }
+            f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
+#if defined(ND_W4_DIAG)
+            if (false) {
+#else
+            if (p.rowbias) {
+#endif
+                const float* rbp = p.rowbias + (size_t)img * p.ld_rowbias + nb;
+                if (vec) rbv = *reinterpret_cast<const f32x4*>(rbp);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (nb + c < p.N) rbv[c] = rbp[c];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    f32x4 yv = (a == 0) ? (rr[0][b2] + rr[1][b2] + rr[2][b2]) : (rr[1][b2] - rr[2][b2] - rr[3][b2]);
+                    const int oy = oy0 + 2 * tyy + a, ox = ox0 + 2 * txx + b2;
+                    if (oy < p.H && ox < p.W) {
+                        float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
+                        const float* rp = nullptr;
+                        if (p.res) {
+                            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                                        : ((size_t)(img * p.H + oy) * p.W + ox);
+                            rp = p.res + rpx * p.ldr + nb;
+                        }
+                        if (vec) {
+                            // the association of conv_wino16_kernel's vector path: ((y + bias) + rowbias) + residual
+                            if (p.bias) yv += bv;
+#if !defined(ND_W4_DIAG)
+                            if (p.rowbias) yv += rbv;
+#endif
+                            if (rp) yv += *reinterpret_cast<const f32x4*>(rp);
+                            if (p.silu_out) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
+                            }
+                            *reinterpret_cast<f32x4*>(op) = yv;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (nb + c < p.N) {
+                                    float v2 = yv[c];
+                                    if (p.bias) v2 += bv[c];
+#if !defined(ND_W4_DIAG)
+                                    if (p.rowbias) v2 += rbv[c];
+#endif
+                                    if (rp) v2 += rp[c];
+                                    if (p.silu_out) v2 = fast_silu(v2);
+                                    op[c] = v2;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#if defined(ND_W4_DIAG)
+    if (tid == 0 && p.rowbias) {
+        unsigned* dg = reinterpret_cast<unsigned*>(const_cast<float*>(p.rowbias)) + (size_t)blockIdx.x * 8;
+        const unsigned long long dg_t3 = __builtin_amdgcn_s_memrealtime();
+        dg[0] = (unsigned)dg_t0; dg[1] = (unsigned)(dg_t1 - dg_t0); dg[2] = (unsigned)(dg_t2 - dg_t0); dg[3] = (unsigned)(dg_t3 - dg_t0);
+        dg[4] = (unsigned)(dg_c2 - dg_c1);
+        dg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+        dg[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+        dg[7] = (unsigned)(dg_t0 >> 32);
+    }
+#endif
+}
+
+int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino4_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3(grid), dim3(256), lds, s, a);
+    return check_launch("nd_conv3x3_winograd_nhwc");
+}
+
+}  // namespace nd
