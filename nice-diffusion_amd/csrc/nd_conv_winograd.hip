@@ -1561,6 +1561,8 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         // conv_wino4_kernel addresses its input through buffer descriptors: 32-bit byte offsets with the range check as
         // zero padding, whole 32-channel chunks on either side of the concatenation seam
         ND_REQUIRE(((C0 + C1) & 31) == 0 && (C1 == 0 || (C0 & 31) == 0), fn, "the two-blocks-per-CU variant needs whole 32-channel chunks");
+        ND_REQUIRE((long)NI * (H >> up) * (W >> up) < (1L << 24) && ldx0 < (1 << 22) && ldx1 < (1 << 22), fn,
+                   "the two-blocks-per-CU variant uses 24-bit multiplies for pixel indices");
         ND_REQUIRE((long)NI * (H >> up) * (W >> up) * ldx0 * 4 < (1L << 31) && (C1 == 0 || (long)NI * (H >> up) * (W >> up) * ldx1 * 4 < (1L << 31)), fn,
                    "the two-blocks-per-CU variant needs input tensors of less than 2 GiB");
         lds = (size_t)64 * 1024;          // two 28 KiB halo buffers; the epilogue exchange takes all 64 KiB (two blocks per CU)

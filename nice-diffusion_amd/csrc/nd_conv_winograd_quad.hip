@@ -25,6 +25,43 @@
 
 namespace nd {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 arithmetic for the input transform (ND_W4_PK: two lanes' worth of work per vector instruction)
+__device__ __forceinline__ f32x4 pk_fma(f32x2 s, f32x4 b, f32x4 a) {          // a + s * b
+#if defined(ND_W4_PK)
+    f32x2 lo, hi;
+    const f32x2 b0 = {b[0], b[1]}, b1 = {b[2], b[3]}, a0 = {a[0], a[1]}, a1 = {a[2], a[3]};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s), "v"(b0), "v"(a0));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s), "v"(b1), "v"(a1));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+    return a + s[0] * b;
+#endif
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+#if defined(ND_W4_PK)
+    f32x2 lo, hi;
+    const f32x2 b0 = {b[0], b[1]}, b1 = {b[2], b[3]}, a0 = {a[0], a[1]}, a1 = {a[2], a[3]};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a0), "v"(b0));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a1), "v"(b1));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+    return a - b;
+#endif
+}
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
+#if defined(ND_W4_PK)
+    f32x2 lo, hi;
+    const f32x2 b0 = {b[0], b[1]}, b1 = {b[2], b[3]}, a0 = {a[0], a[1]}, a1 = {a[2], a[3]};
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(a0), "v"(b0));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(a1), "v"(b1));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+    return a + b;
+#endif
+}
+
 __global__ void __launch_bounds__(256, 2)
     conv_wino4_kernel(const ConvArgs p) {
     constexpr int BN = 64;
@@ -91,20 +128,21 @@ __global__ void __launch_bounds__(256, 2)
     for (int k = 0; k < NDMA; ++k) {
         const int U = (k * 4 + xi) * 64 + lane;
         const int hp0 = (U >> 4) * 2;
-        const int li = (int)(((unsigned)hp0 * mHPI) >> 16);
-        const int rem = hp0 - li * HPI;
-        const int hy = (int)(((unsigned)rem * mHW) >> 16);
-        const int hx0 = rem - hy * HW;              // even; the pair (hx0, hx0 + 1) shares the swizzle key
+        // (24-bit multiplies throughout: full-rate instructions; every operand is < 2^24 by the host's checks)
+        const int li = (int)(__umul24((unsigned)hp0, mHPI) >> 16);
+        const int rem = hp0 - __mul24(li, HPI);
+        const int hy = (int)(__umul24((unsigned)rem, mHW) >> 16);
+        const int hx0 = rem - __mul24(hy, HW);              // even; the pair (hx0, hx0 + 1) shares the swizzle key
         const int key = (((hy >> 1) & 3) << 2) | ((hx0 >> 1) & 3);
         const int t = (U & 15) ^ key;
         const int hx = hx0 + (t >> 3);
         const int img = img0 + li;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
         const bool ok = hp0 < HP && img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const unsigned pix = (unsigned)((img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up));
+        const unsigned pix = (unsigned)(__mul24(__mul24(img, p.Hs) + (iy >> p.up), p.Ws) + (ix >> p.up));
         const unsigned sl16 = (unsigned)(t & 7) << 4;
-        vo0[k] = ok ? (pix * (unsigned)p.ldx0 * 4u + sl16) : kOOB;
-        vo1[k] = ok ? (pix * (unsigned)p.ldx1 * 4u + sl16) : kOOB;
+        vo0[k] = ok ? (__umul24(pix, (unsigned)p.ldx0 * 4u) + sl16) : kOOB;
+        vo1[k] = ok ? (__umul24(pix, (unsigned)p.ldx1 * 4u) + sl16) : kOOB;
     }
     const unsigned npix = (unsigned)(p.NI * p.Hs * p.Ws);
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x0), 0, (int)(npix * (unsigned)p.ldx0 * 4u), 0x00020000);
@@ -118,6 +156,9 @@ __global__ void __launch_bounds__(256, 2)
         const int che = ch < p.NC32 - 1 ? ch : p.NC32 - 1;
         const int c0 = che * 32;
         auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + (k * 4 + xi) * 256);
+#if defined(ND_W4_DBG_PASTEND_ZERO)
+        if (ch > p.NC32 - 1) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)kOOB, 0, 0, 0); return; }
+#endif
         if (c0 < p.C0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)vo0[k], c0 * 4, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, (int)vo1[k], (c0 - p.C0) * 4, 0, 0);
 #endif
@@ -127,6 +168,7 @@ __global__ void __launch_bounds__(256, 2)
     const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
     const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
     const float sgn = (xi == 1) ? 1.f : -1.f;
+    const f32x2 sgn2 = {sgn, sgn};
 
     const int twl2 = p.twl - 1, thl2 = p.thl - 1;
     int off_a[4], off_b[4];          // LDS BYTE offsets (k-step 0) of patch rows ra / rb, columns 0..3, of this lane's tile
@@ -311,10 +353,10 @@ __global__ void __launch_bounds__(256, 2)
             load_b_pos(0, fn); ND_SB;
             // ---- position 1: row transform of the next patch as the reads return; k-step 3: DMA rounds 0, 1
             wait_vm(bfr[1][0], bfr[1][1], younger(st, 1));
-            MF(1, 0); rd_wait(a0, b0, 6); tr[0] = a0 + sgn * b0; ND_SB;
-            MF(1, 1); rd_wait(a1, b1, 4); tr[1] = a1 + sgn * b1; ND_SB;
-            MF(1, 2); rd_wait(a2, b2, 2); tr[2] = a2 + sgn * b2; ND_SB;
-            MF(1, 3); rd_wait(a3, b3, 0); tr[3] = a3 + sgn * b3; ND_SB;
+            MF(1, 0); rd_wait(a0, b0, 6); tr[0] = pk_fma(sgn2, b0, a0); ND_SB;
+            MF(1, 1); rd_wait(a1, b1, 4); tr[1] = pk_fma(sgn2, b1, a1); ND_SB;
+            MF(1, 2); rd_wait(a2, b2, 2); tr[2] = pk_fma(sgn2, b2, a2); ND_SB;
+            MF(1, 3); rd_wait(a3, b3, 0); tr[3] = pk_fma(sgn2, b3, a3); ND_SB;
             MF(1, 4); ND_SB;
             MF(1, 5); if (dma) halo_issue(0, ch + 2, dbuf); ND_SB;
             MF(1, 6); ND_SB;
@@ -322,8 +364,8 @@ __global__ void __launch_bounds__(256, 2)
             load_b_pos(1, fn); ND_SB;
             // ---- position 2: v[0], v[1] of the next k-step replace the ones positions 0, 1 have consumed; DMA rounds 2, 3, 4
             wait_vm(bfr[2][0], bfr[2][1], younger(st, 2));
-            MF(2, 0); v[0] = tr[0] - tr[2]; ND_SB;
-            MF(2, 1); v[1] = tr[1] + tr[2]; ND_SB;
+            MF(2, 0); v[0] = pk_sub(tr[0], tr[2]); ND_SB;
+            MF(2, 1); v[1] = pk_add(tr[1], tr[2]); ND_SB;
             MF(2, 2); ND_SB;
             MF(2, 3); if (dma) halo_issue(2, ch + 2, dbuf); ND_SB;
             MF(2, 4); ND_SB;
@@ -333,14 +375,14 @@ __global__ void __launch_bounds__(256, 2)
             load_b_pos(2, fn); ND_SB;
             // ---- position 3: v[2]; DMA rounds 5, 6; v[3] behind the last MFMA that reads the old one
             wait_vm(bfr[3][0], bfr[3][1], younger(st, 3));
-            MF(3, 0); v[2] = tr[2] - tr[1]; ND_SB;
+            MF(3, 0); v[2] = pk_sub(tr[2], tr[1]); ND_SB;
             MF(3, 1); ND_SB;
             MF(3, 2); if (dma) halo_issue(5, ch + 2, dbuf); ND_SB;
             MF(3, 3); ND_SB;
             MF(3, 4); if (dma) halo_issue(6, ch + 2, dbuf); ND_SB;
             MF(3, 5); ND_SB;
             MF(3, 6); ND_SB;
-            MF(3, 7); v[3] = tr[1] - tr[3]; ND_SB;
+            MF(3, 7); v[3] = pk_sub(tr[1], tr[3]); ND_SB;
             load_b_pos(3, fn); ND_SB;
             if (st == 2) {
                 // every read of this chunk's buffer has returned (k-step 3's were consumed above); chunk ch + 1 (issued a whole
@@ -371,7 +413,18 @@ __global__ void __launch_bounds__(256, 2)
     //      channels of its tile.  r[b] = sum_nu At[b][nu] M[xi][nu]  (At = [[1,1,1,0],[0,1,-1,-1]]) is formed in registers
     //      and exchanged through LDS as ex[n][xi][b][g4][lane][4] (64 KiB, one round); wave w then finishes register
     //      group w of both n tiles for all four xi: Y[a][b] = sum_xi At[a][xi] r_xi[b] -> 2x2 pixels x 4 channels per lane.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // run-ahead weight loads / patch reads have landed
+    // The run-ahead fragment loads of the last k-step are still in flight and hipcc cannot know it (they are inline ISA):
+    // without the operands below it re-uses their destination registers for the epilogue's sums right away and the data
+    // that arrives later lands on top of them (seen as run-to-run differences on cache-friendly inputs).  Tying all
+    // eight fragments to the wait keeps the registers allocated until every load has returned.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[2][0]), "+v"(bfr[2][1]),
+                   "+v"(bfr[3][0]), "+v"(bfr[3][1])
+                 :
+                 : "memory");
+#if defined(ND_W4_DBG_SLEEP)
+    asm volatile("s_sleep 127\ns_sleep 127\ns_sleep 127\ns_sleep 127\ns_sleep 127\ns_sleep 127\ns_sleep 127\ns_sleep 127" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the halo buffers
     float* ex = smem;
 #pragma unroll

@@ -181,6 +181,34 @@ def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W, o
     assert torch.equal(out2, outs[1])
 
 
+@pytest.mark.parametrize('NI,H,W,C0,C1,N,up', [(4, 128, 128, 64, 0, 256, 1), (8, 64, 64, 192, 0, 192, 1), (4, 64, 64, 64, 64, 256, 0)])
+def test_conv3x3_winograd_two_blocks_per_cu_run_to_run(NI, H, W, C0, C1, N, up):
+    """conv_wino4_kernel issues its operand loads as inline ISA with hand-counted waits.  A first version let hipcc re-use
+    the destination registers of the run-ahead fragment loads of the last k-step before they had returned: results
+    changed from run to run on cache-friendly inputs (nearest-2x input, several n blocks per m tile, short K).  Twelve
+    launches in changing cache states must all give the bits of conv_wino16_kernel."""
+    names = [lib().nd_conv_winograd_variant_name(v) for v in range(lib().nd_conv_winograd_num_variants())]
+    v1, v4 = names.index(b'nd::conv_wino16_kernel<1>'), names.index(b'nd::conv_wino4_kernel')
+    Hs, Ws = H >> up, W >> up
+    xa, xb = rnd(NI, C0, Hs, Ws, seed=1), rnd(NI, max(C1, 4), Hs, Ws, seed=2)
+    w, b = rnd(N, C0 + C1, 3, 3, seed=3, scale=0.05), rnd(N, seed=4)
+    res = rnd(NI, N, H, W, seed=5)
+    wd, xad, xbd, bd, resd = pack_wino(w), nhwc(xa), nhwc(xb), b.to(DEV), nhwc(res)
+    junk = torch.zeros(32 << 20, device=DEV)
+
+    def run(v):
+        out = torch.full((NI * H * W * N,), float('nan'), device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr() if C1 else None, C1, C1, wd.data_ptr(),
+                                                  bd.data_ptr(), None, 0, resd.data_ptr(), N, out.data_ptr(), N, NI, H, W, N,
+                                                  _hip.CONV_IN_UP2X if up else 0, v, None, None, 0, st()))
+        return out
+    ref = run(v1)
+    for i in range(12):
+        if i % 3 == 1:
+            junk.add_(1.0)          # evict: the next launch starts from another cache state
+        assert torch.equal(run(v4), ref), i
+
+
 def test_conv3x3_winograd_fused_options():
     B, C0, C1, Cout, H, W = 2, 64, 32, 64, 8, 8
     xa, xb = rnd(B, C0, H, W, seed=1), rnd(B, C1, H, W, seed=2)
