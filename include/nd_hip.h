@@ -120,6 +120,9 @@ int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int* threads, i
 /* The variant's kernel as a profiler prints it, e.g. "nd::conv_wino16_kernel<1>" ("" for a bad variant). */
 const char* nd_conv_winograd_variant_name(int variant);
 int64_t nd_conv_winograd_weight_floats(int N, int C);
+/* Upper bound, in floats, of what a launch of `variant` (< 0: any variant) may read of the packed tensor: the chunks it
+ * consumes plus its read-ahead (csrc/nd_weight_stream.h).  Always <= nd_conv_winograd_weight_floats(N, C). */
+int64_t nd_conv_winograd_max_weight_read(int variant, int N, int C);
 int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream);
 int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                              const float* w, const float* bias, const float* rowbias, int ld_rowbias,
@@ -141,6 +144,9 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
 int nd_conv_bf16_num_variants(void);
 int nd_conv_bf16_variant_info(int variant, int* bm, int* bn, int* threads);
 int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize);
+/* Upper bound, in elements, of what a launch of `variant` (< 0: any) with `splits` splits over K may read of the packed
+ * tensor (read-ahead and split-K's shifted pointers included).  Always <= nd_conv_bf16_weight_elems(N, C, ksize). */
+int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int ksize, int splits);
 /* layout 0: fragments of v_mfma_f32_32x32x16_bf16; layout 1: of v_mfma_f32_16x16x32_bf16 -- a variant takes the layout
  * nd_conv_bf16_variant_layout(variant) names (0 for variant < 0); both have nd_conv_bf16_weight_elems elements. */
 int nd_conv_bf16_variant_layout(int variant);
@@ -160,6 +166,9 @@ int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1,
  * floats), a second kernel adds them in split order (deterministic) with bias / rowbias / residual / SiLU and writes bf16.
  * Plain bf16 output only: no fused GroupNorm, output statistics, 2x-upsampled reads or LDS-DMA variants; the tile variant
  * must be named; fewer splits are used when the layer has fewer chunks (error if that leaves one). */
+/* fp32 words of `workspace` a nd_conv_bf16_splitk_nhwc launch of this shape uses (C = C0 + C1; negative: bad arguments or
+ * too few input channels for two splits). */
+int64_t nd_conv_bf16_splitk_workspace_floats(int NI, int H, int W, int N, int C, int ksize, int splits);
 int nd_conv_bf16_splitk_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                              const void* w, const float* bias, const float* rowbias, int ld_rowbias,
                              const void* residual, int ldr, void* out, int ldo,
@@ -188,6 +197,9 @@ int nd_conv_direct_nhwc(const float* x, int C, int ldx, const float* w_oihw, con
  * k = 1 case) -> MFMA-fragment order [c32][n tile][tap][kc][lane][4], zero padded, so that every B operand of the
  * matrix instruction is one coalesced 1 KiB load.  w_out must hold nd_conv_weight_floats(N, C, ksize) floats. */
 int64_t nd_conv_weight_floats(int N, int C, int ksize);
+/* Upper bound, in floats, of what a launch of `variant` (< 0: any) may read of the packed tensor (read-ahead included).
+ * Always <= nd_conv_weight_floats(N, C, ksize). */
+int64_t nd_conv_max_weight_read(int variant, int N, int C, int ksize);
 int nd_repack_conv_weight(const float* w_oihw, float* w_out, int N, int C, int ksize, nd_stream_t stream);
 
 /* ---- K3/K4: GroupNorm(32 groups) over NHWC, input = concat(x0, x1); activations fp32 or bf16 (`dtype`) ---------

@@ -257,10 +257,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // register set -- the slot of tile mi for the NEXT k-step is re-read right behind the MFMAs that consumed it and has
     // the other TM-1 tiles' MFMAs (>= 190 cycles) to land; 128 accumulator + 16 + 24 operand registers leave room for
     // two waves per SIMD.
-    constexpr int RING = (TAPS == 9) ? 3 : 4;      // measured: deeper rings (6 / 8 on the small register tiles) are slower
+    constexpr int RING = wstream::bf16_ring(TAPS);      // measured: deeper rings (6 / 8 on the small register tiles) are slower
     constexpr int BDIST = RING - 1;
+    static_assert(STEPS == wstream::bf16_steps(TAPS) &&
+                  wstream::pad_chunks(BDIST, STEPS) <= wstream::kBf16PadChunks, "weight read-ahead exceeds the packer's zero padding");
     f32x4 a_fr[TM], b_fr[RING][TN];
-    // the packed buffer carries a whole zero chunk at the end, so the stream may always run ahead
+    // the packed buffer ends in wstream::kBf16PadChunks zero chunks; the static_assert above is what lets the stream run
+    // BDIST fragments past the last real one (split-K shifts the pointer by whole chunks and ends on a chunk boundary)
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
@@ -706,10 +709,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // register set -- the slot of tile mi for the NEXT k-step is re-read right behind the MFMAs that consumed it and has
     // the other TM-1 tiles' MFMAs (>= 190 cycles) to land; 128 accumulator + 16 + 24 operand registers leave room for
     // two waves per SIMD.
-    constexpr int RING = (TN >= 4) ? 2 : ((TAPS == 9) ? 3 : 4);      // divides the 6 / 4 unrolled k-steps; k-steps are 32 channels here
+    constexpr int RING = wstream::bf16s_ring(TN, TAPS);      // divides the 6 / 4 unrolled k-steps; k-steps are 32 channels here
     constexpr int BDIST = RING - 1;
+    static_assert(STEPS == wstream::bf16s_steps(TAPS) &&
+                  wstream::pad_chunks(BDIST, STEPS) <= wstream::kBf16PadChunks, "weight read-ahead exceeds the packer's zero padding");
     f32x4 a_fr[TM], b_fr[RING][TN];
-    // the packed buffer carries a whole zero chunk at the end, so the stream may always run ahead
+    // the packed buffer ends in wstream::kBf16PadChunks zero chunks (a 1x1 stream of this layout has only 2 fragments per
+    // chunk and n tile, so its ring of 4 reaches into the SECOND padding chunk: the static_assert above covers it)
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
@@ -923,6 +929,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
+// LDS-DMA: 16 bytes per lane from a per-lane global address into LDS at M0 + lane * 16 (gemm_bf16_kernel; conv_bf16w_kernel)
+#define ND_GLDS16H(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// ---- An experiment that measures EQUAL to the register-streamed form: compiled only with
+//      `make EXPERIMENTAL=1`; without it variants 12 / 13 stay reserved and a launch reports "not built".
+#if defined(ND_EXPERIMENTAL_KERNELS)
 // ------------------------------------------------------------------------------------------------------------
 // 3x3 form with BOTH operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write).
 // Ablations of the kernel above put the weight-fragment stream (global -> VGPR per wave, two waves fetching every
@@ -931,9 +945,6 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 // two LDS stages while the previous stage is consumed; the next chunk's halo goes the same way, one 1 KiB piece per wave
 // and tap, with the XOR swizzle applied to the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  One
 // "vmcnt(0) + barrier" per tap publishes everything issued during the tap; nothing is counted by hand.
-#define ND_GLDS16H(gptr, lptr)                                                                             \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
@@ -1189,6 +1200,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         }
     }
 }
+
+#endif  // ND_EXPERIMENTAL_KERNELS
 
 // ------------------------------------------------------------------------------------------------------------
 // GEMM-shaped 1x1 form (flat pixel list): out[M][N] = x[M][K] . w[N][K]^T with K of a few hundred.  In the conv-shaped
@@ -1585,6 +1598,7 @@ static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     return check_launch("nd_conv_bf16_nhwc");
 }
 
+#if defined(ND_EXPERIMENTAL_KERNELS)
 template <int WM, int WN, int TM, int TN>
 static int launch_w(const ConvArgsH& a, const __bf16* zero16, int grid, size_t lds, hipStream_t s) {
     auto kern = conv_bf16w_kernel<WM, WN, TM, TN>;
@@ -1593,6 +1607,7 @@ static int launch_w(const ConvArgsH& a, const __bf16* zero16, int grid, size_t l
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a, zero16);
     return check_launch("nd_conv_bf16_nhwc");
 }
+#endif  // ND_EXPERIMENTAL_KERNELS
 
 template <int WM, int WN, int TM, int TN, int TAPS>
 static int launch_s(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
@@ -1672,9 +1687,40 @@ extern "C" int nd_conv_bf16_variant_info(int variant, int* bm, int* bn, int* thr
 extern "C" int64_t nd_conv_bf16_weight_elems(int N, int C, int ksize) {
     if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3)) return ND_E_ARG;
     const int64_t nt32 = (N + 31) / 32;
-    // + 2 chunks of zeros: the fragment stream runs up to 3 fragments ahead of the last real one, and a 16x16x32 1x1 stream
-    // has only 2 fragments per chunk and n tile (a single padding chunk was overrun by one fragment there)
-    return (int64_t)(nc64_padded(C) + 2) * nt32 * ksize * ksize * 4 * 512;
+    // + kBf16PadChunks chunks of zeros: the fragment stream runs up to 3 fragments ahead of the last real one, and a
+    // 16x16x32 1x1 stream has only 2 fragments per chunk and n tile (nd_weight_stream.h; every kernel static_asserts its ring)
+    return (int64_t)(nc64_padded(C) + wstream::kBf16PadChunks) * nt32 * ksize * ksize * 4 * 512;
+}
+
+// Upper bound (in elements) of what a launch of `variant` (< 0: any) with `splits` splits over K may read of a packed
+// tensor.  Split s shifts the weight pointer by s * kchunks whole chunks and consumes at most kchunks of them (a
+// multiple of the LDS chunk), so every split ends on a chunk boundary <= nc64_padded(C); the read-ahead goes on from there.
+extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int ksize, int splits) {
+    if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3) || variant >= kNumVariantsH || splits < 1) return ND_E_ARG;
+    const int taps = ksize * ksize;
+    const int64_t nt32 = (N + 31) / 32;
+    int pad = 0;
+    for (int v = 0; v < kNumVariantsH; ++v) {
+        if (variant >= 0 && v != variant) continue;
+        const VariantH& V = kVariantsH[v];
+        int p;
+        if (V.ldsw == 2) p = 0;                                                                   // gemm_bf16_kernel: real chunks only
+        else if (V.ldsw == 1) p = wstream::pad_chunks(wstream::kBf16DmaAheadTaps, taps);           // conv_bf16w_kernel
+        else if (V.mf) p = wstream::pad_chunks(wstream::bf16s_ring(V.tn, taps) - 1, wstream::bf16s_steps(taps));
+        else p = wstream::pad_chunks(wstream::bf16_ring(taps) - 1, wstream::bf16_steps(taps));
+        pad = p > pad ? p : pad;
+    }
+    int consumed = nc64_padded(C);
+    if (splits > 1) {                                     // the host's split plan (nd_conv_bf16_splitk_nhwc)
+        const int nc64 = (C + 63) / 64, unit = taps == 9 ? 1 : 2;
+        int kc = (nc64 + splits - 1) / splits;
+        kc = (kc + unit - 1) / unit * unit;
+        const int S = (nc64 + kc - 1) / kc;
+        const int last = nc64 - (S - 1) * kc;                                   // chunks of the last split ...
+        const int end = (S - 1) * kc + (last + unit - 1) / unit * unit;         // ... rounded up to whole LDS chunks by the kernel
+        consumed = end > consumed ? end : consumed;
+    }
+    return (int64_t)(consumed + pad) * nt32 * taps * 4 * 512;
 }
 
 extern "C" const char* nd_conv_bf16_variant_name(int variant) {
@@ -1836,11 +1882,16 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
         // 16 bytes of zeros for padded halo units: the tail of the packed weights' trailing zero chunk
         const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;
         const size_t ldsw = lds_bytes_w(V, tp.hp);
+#if defined(ND_EXPERIMENTAL_KERNELS)
         switch (v) {
             case 12: return launch_w<2, 4, 4, 2>(a, zero16, grid, ldsw, s);
             case 13: return launch_w<2, 4, 2, 2>(a, zero16, grid, ldsw, s);
         }
         return fail_arg(fn, "bad variant");
+#else
+        (void)zero16; (void)ldsw;
+        return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
+#endif
     }
     const size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
     if (chstats) return dispatch_h_stats(v, a, grid, lds, s);
@@ -1871,9 +1922,21 @@ extern "C" int nd_conv_bf16_splitk_nhwc(const void* x0, int C0, int ldx0, const 
                                         float* workspace, nd_stream_t stream) {
     const char* fn = "nd_conv_bf16_splitk_nhwc";
     ND_REQUIRE(splits >= 2 && splits <= 16 && workspace != nullptr && variant >= 0, fn,
-               "2..16 splits, a workspace of splits * NI*H*W * N floats, and a named tile variant");
+               "2..16 splits, a workspace of nd_conv_bf16_splitk_workspace_floats() floats, and a named tile variant");
     return conv_bf16_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
                           NI, H, W, N, ksize, flags, variant, nullptr, nullptr, 0, nullptr, false, stream, splits, workspace);
+}
+
+// fp32 words nd_conv_bf16_splitk_nhwc writes to (and its reduce kernel reads from) `workspace`: one [NI*H*W][N] slab
+// of raw accumulators per split actually used -- fewer than asked for when the layer has fewer LDS chunks
+extern "C" int64_t nd_conv_bf16_splitk_workspace_floats(int NI, int H, int W, int N, int C, int ksize, int splits) {
+    if (NI <= 0 || H <= 0 || W <= 0 || N <= 0 || C <= 0 || (ksize != 1 && ksize != 3) || splits < 2 || splits > 16) return ND_E_ARG;
+    const int nc64 = (C + 63) / 64, unit = ksize == 3 ? 1 : 2;
+    int kc = (nc64 + splits - 1) / splits;
+    kc = (kc + unit - 1) / unit * unit;
+    const int S = (nc64 + kc - 1) / kc;          // the split plan of conv_bf16_impl
+    if (S < 2) return ND_E_ARG;
+    return (int64_t)S * NI * H * W * N;
 }
 
 extern "C" int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant) {

@@ -164,9 +164,10 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     // operand registers: A ping-pong by k-step parity; B ring of 4 (one per k-step of a tap), fetched BDIST steps ahead
-    constexpr int BDIST = (TAPS == 9) ? 1 : 3;     // measured: deeper prefetch only pays for the short-K 1x1 form
+    constexpr int BDIST = wstream::f32_conv_ahead(TAPS);     // measured: deeper prefetch only pays for the short-K 1x1 form
+    static_assert(wstream::pad_chunks(BDIST, TAPS * 4) <= wstream::kF32PadChunks, "weight read-ahead exceeds the packer's zero padding");
     f32x4 a_pp[2][TM], b_pp[4][TN];
-    // the packed buffer carries one zero c32 block of padding at the end, so the stream may always run one ahead
+    // the packed buffer ends in wstream::kF32PadChunks zero chunks: the static_assert above is what lets the stream run ahead
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #if defined(ND_ABL_NOB)
         (void)dst;     // timing-only ablation: B operands stay whatever the registers hold
@@ -416,7 +417,8 @@ __global__ void __launch_bounds__(WM* WN * 64, GN ? 2 : OCC)
     gemm_stream_kernel(const ConvArgs p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int D = 3;                               // prefetch distance in k-steps (ring of 4)
+    constexpr int D = wstream::kF32StreamAhead;        // prefetch distance in k-steps (ring of 4)
+    static_assert(wstream::pad_chunks(D, 4) <= wstream::kF32PadChunks, "weight read-ahead exceeds the packer's zero padding");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -757,7 +759,22 @@ extern "C" int nd_conv_num_variants(void) { return kNumVariants; }
 extern "C" int64_t nd_conv_weight_floats(int N, int C, int ksize) {
     if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3)) return ND_E_ARG;
     const int64_t nt32 = (N + 31) / 32;
-    return (int64_t)(nc32_padded(C) + 1) * nt32 * ksize * ksize * 4 * 256;
+    return (int64_t)(nc32_padded(C) + wstream::kF32PadChunks) * nt32 * ksize * ksize * 4 * 256;
+}
+
+// Upper bound (in floats) of what a launch of `variant` (< 0: any) may read of a packed tensor: the chunks it consumes plus
+// its read-ahead, by the expressions the kernels static_assert on (nd_weight_stream.h)
+extern "C" int64_t nd_conv_max_weight_read(int variant, int N, int C, int ksize) {
+    if (N <= 0 || C <= 0 || (ksize != 1 && ksize != 3) || variant >= kNumVariants) return ND_E_ARG;
+    const int taps = ksize * ksize;
+    const int64_t nt32 = (N + 31) / 32;
+    int ahead = 0;
+    for (int v = 0; v < kNumVariants; ++v) {
+        if (variant >= 0 && v != variant) continue;
+        const int a = v < kFirstStream ? wstream::f32_conv_ahead(taps) : (v < 13 ? wstream::kF32StreamAhead : wstream::kF32GemmAhead);
+        ahead = a > ahead ? a : ahead;
+    }
+    return (int64_t)(nc32_padded(C) + wstream::pad_chunks(ahead, taps * 4)) * nt32 * taps * 4 * 256;
 }
 
 extern "C" int nd_repack_conv_weight(const float* w, float* w_out, int N, int C, int ksize, nd_stream_t stream) {

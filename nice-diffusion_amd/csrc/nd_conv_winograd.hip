@@ -169,6 +169,8 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
             for (int e = 0; e < 16; ++e) acc[mt][nu][e] = 0.f;
 
     f32x4 bfr[2][4];      // [k-step parity][nu]
+    static_assert(wstream::pad_chunks(wstream::kWinoAhead, wstream::kWinoStepsPerChunk) <= wstream::kWinoPadChunks,
+                  "weight read-ahead exceeds the packer's zero padding");
     auto load_b = [&](f32x4 (&dst)[4], int c32, int kc) {
         const float* q = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
 #if !defined(ND_WABL_NOB)
@@ -725,6 +727,11 @@ __global__ void __launch_bounds__(1024, 4)
     }
 }
 
+// ---- Experiments that were built, are bit-identical to conv_wino16_kernel, and measure SLOWER: the
+//      persistent form (variant 10) and the LDS-DMA operand streams (variant 9).  They are compiled only with
+//      `make EXPERIMENTAL=1` (-DND_EXPERIMENTAL_KERNELS); without it their variant numbers stay reserved and a launch
+//      reports "not built".  tests/ exercise them when they are built.
+#if defined(ND_EXPERIMENTAL_KERNELS)
 // ------------------------------------------------------------------------------------------------------------
 // Persistent form of conv_wino16_kernel: one block per CU walks several tiles.  A 16-wave block owns its CU (154 KB of
 // LDS), so in the one-tile-per-block form nothing overlaps a tile's prologue (first halo chunk + first weight
@@ -1219,6 +1226,8 @@ __global__ void __launch_bounds__(1024, 4)
     const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
     float* ring = smem + RING0 + wave * (2 * WNT * 256);      // this wave's 2 slots x 3 fragments
     // fragments of global k-step gs = 4*c32 + kc go to ring slot gs & 1
+    static_assert(wstream::pad_chunks(wstream::kWinoDmaAhead, wstream::kWinoStepsPerChunk) <= wstream::kWinoPadChunks,
+                  "weight read-ahead exceeds the packer's zero padding");
     auto issue_b = [&](int gs) {
         const float* qq = bp + (size_t)(gs >> 2) * c32_stride + (gs & 3) * (16 * 256);
 #pragma unroll
@@ -1358,6 +1367,8 @@ __global__ void __launch_bounds__(1024, 4)
     }
 }
 
+#endif  // ND_EXPERIMENTAL_KERNELS
+
 // OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
 __global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -1456,7 +1467,22 @@ extern "C" int nd_conv_winograd_variant_info(int variant, int* bm, int* bn, int*
 
 extern "C" int64_t nd_conv_winograd_weight_floats(int N, int C) {
     if (N <= 0 || C <= 0) return ND_E_ARG;
-    return (int64_t)((C + 31) / 32 + 1) * ((N + 31) / 32) * 64 * 256;
+    return (int64_t)((C + 31) / 32 + wstream::kWinoPadChunks) * ((N + 31) / 32) * 64 * 256;
+}
+
+// Upper bound (in floats) of what a launch of `variant` (< 0: any) may read of a packed tensor (nd_weight_stream.h)
+extern "C" int64_t nd_conv_winograd_max_weight_read(int variant, int N, int C) {
+    if (N <= 0 || C <= 0 || variant >= kNumWino) return ND_E_ARG;
+    int ahead = 0;
+    for (int v = 0; v < kNumWino; ++v) {
+        if (variant >= 0 && v != variant) continue;
+        const int code = kWinoCfg[v][3];
+        const int a = code == 5 ? wstream::kWinoDmaAhead : (code == 7 ? wstream::kWinoWaveAhead : wstream::kWinoAhead);
+        ahead = a > ahead ? a : ahead;
+    }
+    // (a chunk pair of the NSUB = 2 forms ends on the last REAL 32-channel chunk: k-steps past it are skipped, so the
+    // consumed range is ceil(C / 32) chunks for every form)
+    return (int64_t)((C + 31) / 32 + wstream::pad_chunks(ahead, wstream::kWinoStepsPerChunk)) * ((N + 31) / 32) * 64 * 256;
 }
 
 extern "C" int nd_repack_conv_weight_winograd(const float* w_oihw, float* w_out, int N, int C, nd_stream_t stream) {
@@ -1587,8 +1613,9 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
-        case 11: return launch_winow(a, grid, lds, s);
         case 12: return launch_wino4(a, grid, lds, s);
+#if defined(ND_EXPERIMENTAL_KERNELS)
+        case 11: return launch_winow(a, grid, lds, s);
         case 10: {
             static bool attr_set[kMaxDevices] = {};
             if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino16p_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
@@ -1604,6 +1631,10 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
             hipLaunchKernelGGL(conv_wino16g_kernel, dim3(grid), dim3(1024), lds, s, a);
             return check_launch(fn);
         }
+#else
+        case 9: case 10: case 11:
+            return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
+#endif
     }
     return fail_arg(fn, "bad variant");
 }

@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(256, 2)
     //      pipe: tools/wino4_timeline.py measured 76 cycles per MFMA for a stream of MFMAs with 3 VALU each, and the
     //      per-lane address arithmetic of the first version, 28 VALU per DMA, cost 10 % of the kernel.)  Zero padding is
     //      the buffer's range check: lanes outside the image carry an offset past num_records and the DMA writes zeros.
-    const int Ctot = p.C0 + p.C1;
     constexpr unsigned kOOB = 0x80000000u;          // the host admits tensors of < 2 GiB
     const unsigned mHPI = 65536u / (unsigned)HPI + 1u, mHW = 65536u / (unsigned)HW + 1u;       // n / d = (n * m) >> 16 for n < 65536 / d
     unsigned vo0[NDMA], vo1[NDMA];
@@ -219,7 +218,9 @@ __global__ void __launch_bounds__(256, 2)
         if (st == 3) for (int m = 0; m < nu; ++m) y += kDmaInPos[m];        // DMAs of this k-step 3 so far
         return y;
     };
-    f32x4 bfr[4][2];      // [nu][n tile]: re-loaded in place, one position at a time
+    f32x4 bfr[4][2];      // [nu][n tile]: re-loaded in place, one position at a time (one k-step of read-ahead)
+    static_assert(wstream::pad_chunks(wstream::kWinoAhead, wstream::kWinoStepsPerChunk) <= wstream::kWinoPadChunks,
+                  "weight read-ahead exceeds the packer's zero padding");
     const int voff = lane * 16;                                          // byte offset of this lane inside a 1 KiB fragment
     const float* bw0 = p.w + ((size_t)ntile0 * FRAGS + 4 * xi) * 256;      // wave-uniform: SGPR base + VGPR lane offset
     const float* bw1 = bw0 + noff1;

@@ -16,6 +16,8 @@
 // kernels give the same bits.
 #include "nd_conv_common.h"
 
+#if defined(ND_EXPERIMENTAL_KERNELS)      // an experiment that measures slower: built with `make EXPERIMENTAL=1` only
+
 #ifndef ND_WINOW_SCHED
 #define ND_WINOW_SCHED 1
 #endif
@@ -370,3 +372,5 @@ int launch_winow(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
 }
 
 }  // namespace nd
+
+#endif  // ND_EXPERIMENTAL_KERNELS

@@ -398,7 +398,10 @@ class UNetPlan:
         if isinstance(mode, tuple):
             # too few output tiles to fill the chip: split over K into a shared fp32 workspace + a deterministic reduce
             splits = mode[1]
-            self._splitk_floats = max(self._splitk_floats, splits * NI * H * W * N)
+            need = self.lib.nd_conv_bf16_splitk_workspace_floats(NI, H, W, N, src.C + C1, ksize, splits)
+            if need <= 0:
+                raise _hip.NdHipError('nd_conv_bf16_splitk_workspace_floats: ' + _hip.last_error())
+            self._splitk_floats = max(self._splitk_floats, need)
             self._emit(self.lib.nd_conv_bf16_splitk_nhwc, head + [var, splits, ('splitk', 0)], label, flops=fl,
                        variant=('bf16', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         elif with_stats:
@@ -427,7 +430,10 @@ class UNetPlan:
         measured statistics pass over the output."""
         if not _autotune_enabled() or flops < 2e8:
             return -1, 'plain'
-        ck = (self.device.index,) + key
+        # the knobs that decide which forms may be chosen are part of the key: a choice tuned (or loaded from an
+        # ND_TUNE_CACHE file) under other settings must not override ND_BF16_SPLITK=0 / ND_BF16_EPILOGUE_STATS=0
+        ck = (self.device.index,) + key + ('sk%d' % _bf16_splitk(), 'es%d' % _bf16_epilogue_stats(),
+                                           'gnnb' + os.environ.get('ND_FUSE_GN_MAXNB', ''))
         if ck in _TUNED:
             c = _TUNED[ck]
             if c[0] == 'bf16+splitk':
@@ -484,6 +490,10 @@ class UNetPlan:
                         t = measure(self.lib.nd_conv3x3_bf16_stats_nhwc, sargs)
                         if sbest_ms is None or t < sbest_ms:
                             sbest, sbest_ms = v, t
+        if best_ms is None:
+            # no tile variant takes this launch with these fused options: leave it to the library's own selection (which
+            # reports the real reason if it cannot run it either); nothing is cached
+            return -1, 'plain'
         choice = ('bf16', best)
         cost = best_ms
         pass_ms = 0.0
@@ -512,7 +522,8 @@ class UNetPlan:
         if _bf16_splitk() and _bf16_epilogue_stats() != 2 and M_ <= 8192 and Cin >= 512 and gn[0] is None and N_ % 4 == 0 and \
                 not (flags_ & (_hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X | _hip.CONV_OUT_F32)):
             splits = (2, 4)           # 8 splits on the 1024-pixel layers measured equal to 4
-            ws = torch.empty(splits[-1] * M_ * N_, dtype=torch.float32, device=self.device)
+            ws = torch.empty(max(self.lib.nd_conv_bf16_splitk_workspace_floats(NI_, H_, W_, N_, Cin, head[18], S) for S in splits),
+                             dtype=torch.float32, device=self.device)
             cands = [best] + [v for v in (19, 7, 5, 11) if v != best and v < self.lib.nd_conv_bf16_num_variants()]
             for v in cands:
                 lay = self.lib.nd_conv_bf16_variant_layout(v)

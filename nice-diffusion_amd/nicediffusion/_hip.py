@@ -76,13 +76,17 @@ _SPECIAL = {
     'nd_version': ([], _i),
     'nd_conv_num_variants': ([], _i),
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
+    'nd_conv_max_weight_read': ([_i, _i, _i, _i], _i64),
     'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
+    'nd_conv_bf16_max_weight_read': ([_i, _i, _i, _i, _i], _i64),
+    'nd_conv_bf16_splitk_workspace_floats': ([_i, _i, _i, _i, _i, _i, _i], _i64),
     'nd_conv_bf16_num_variants': ([], _i),
     'nd_conv_bf16_variant_layout': ([_i], _i),
     'nd_conv_bf16_variant_name': ([_i], ctypes.c_char_p),
     'nd_conv_bf16_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_groupnorm_stats_blocks': ([_i, _i, _i, _i], _i),
     'nd_conv_winograd_weight_floats': ([_i, _i], _i64),
+    'nd_conv_winograd_max_weight_read': ([_i, _i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_winograd_stats_variant': ([], _i),
     'nd_conv_winograd_stats_floats': ([_i, _i, _i, _i, ctypes.POINTER(_i)], _i64),

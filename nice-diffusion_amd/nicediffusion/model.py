@@ -242,8 +242,10 @@ class DiffusionModel(nn.Module):
 
     def _check_labels(self, y):
         """nn.Embedding raises on an out-of-range index (model.py:459); the gather kernel must not clamp silently."""
-        if y is not None and y.numel():
-            lo, hi = int(y.min()), int(y.max())
+        # (ONE device -> host sync per call -- torch.aminmax; ``verify_labels = False`` skips it for callers that have
+        # validated their labels and want forward() free of host synchronisation)
+        if y is not None and y.numel() and getattr(self, 'verify_labels', True):
+            lo, hi = (int(v) for v in torch.aminmax(y))
             if lo < 0 or hi >= self.num_classes:
                 raise IndexError('class label out of range: got [{}, {}], model has {} classes'.format(
                     lo, hi, self.num_classes))

@@ -134,7 +134,7 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
                                          out.data_ptr(), Cout, B, H, W, Cout, ksize, _hip.CONV_OUT_F32 if f32out else 0,
                                          v, None, None, 0, st())
             if rc != 0:
-                assert v >= 0 and 'no tile variant fits' in _hip.last_error(), (v, _hip.last_error())
+                assert v >= 0 and ('no tile variant fits' in _hip.last_error() or 'not built' in _hip.last_error()), (v, _hip.last_error())
                 continue
             ran += 1
             got = from_nhwc(out, B, H, W, Cout)

@@ -119,6 +119,10 @@ def pack_wino(w):
     return out
 
 
+# kernels behind `make EXPERIMENTAL=1` (bit-identical, slower: DESIGN.md section 6); their variant numbers stay reserved
+EXPERIMENTAL_WINO = (b'nd::conv_wino16g_kernel', b'nd::conv_wino16p_kernel', b'nd::conv_winow_kernel')
+
+
 WINO_CASES = [(2, 32, 32, 16, 16), (1, 64, 96, 8, 8), (3, 4, 32, 28, 28), (2, 96, 6, 16, 16), (1, 192, 192, 64, 64),
               (2, 32, 2, 14, 14), (5, 64, 64, 4, 4), (3, 36, 40, 6, 10), (2, 64, 64, 2, 2)]
 
@@ -134,8 +138,10 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
         rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                             None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st())
         if rc != 0:      # the persistent form declines an odd number of 32-channel chunks, the 256-pixel whole-transform-per-wave
-            # form maps so small that 64 tiles span more than 416 halo pixels
+            # form maps so small that 64 tiles span more than 416 halo pixels; the experiments are not in the default build
             name = lib().nd_conv_winograd_variant_name(v)
+            if name in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
+                continue
             assert (name == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()) or \
                 (name == b'nd::conv_winow_kernel' and 'no tiling fits' in _hip.last_error() and H * W <= 16) or \
                 (name == b'nd::conv_wino4_kernel' and 'whole 32-channel chunks' in _hip.last_error() and Cin % 32), (name, _hip.last_error())
@@ -167,9 +173,12 @@ def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W, o
     outs = []
     for v in (v1, vp):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
-        _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), Cin - C0, Cin - C0, wd.data_ptr(),
-                                                  bd.data_ptr(), rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(),
-                                                  Cout, B, H, W, Cout, 0, v, None, None, 0, st()))
+        rc = lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), Cin - C0, Cin - C0, wd.data_ptr(),
+                                            bd.data_ptr(), rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(),
+                                            Cout, B, H, W, Cout, 0, v, None, None, 0, st())
+        if rc != 0 and other in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
+            pytest.skip('experimental kernel: built with make EXPERIMENTAL=1 only')
+        _hip.check(rc)
         outs.append(out.clone())
     assert torch.equal(outs[0], outs[1])
     assert (from_nhwc(outs[1], B, H, W, Cout) - ref).abs().max().item() < 2e-4
@@ -228,8 +237,11 @@ def test_conv3x3_winograd_fused_options():
         rc = lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), C1, C1, wd.data_ptr(), bd.data_ptr(),
                                             rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
                                             Cout, 0, v, None, None, 0, st())
+        name = lib().nd_conv_winograd_variant_name(v)
+        if rc != 0 and name in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
+            continue
         if rc != 0:      # 96 input channels = 3 chunks: the persistent form declines (it is covered by its own test)
-            assert lib().nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
+            assert name == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
         else:
             assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
         out = torch.empty(B * 4 * H * W * Cout, device=DEV)

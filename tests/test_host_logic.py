@@ -220,6 +220,38 @@ def test_library_exports_every_header_symbol():
     assert exported == set(names)
 
 
+def test_weight_read_ahead_stays_inside_the_packed_tensors():
+    """Every kernel that streams packed weights keeps fragment loads in flight past the last chunk it consumes; the packers
+    append zero chunks for that.  csrc/nd_weight_stream.h states the contract (static_asserts in every kernel
+    instantiation); here the per-variant bound nd_conv*_max_weight_read is checked against the allocation size for every
+    variant over a grid of shapes, split-K's shifted pointers included.  (Round 2: a 16x16x32 bf16 1x1 stream read one
+    fragment past a single padding chunk and aborted the process.)"""
+    lib = _hip.load()
+    Ns = (1, 6, 32, 33, 96, 192, 200, 768, 1152, 2304)
+    Cs = (4, 32, 36, 64, 70, 96, 128, 192, 200, 576, 960, 1344, 1536, 2048)
+    for N in Ns:
+        for C in Cs:
+            for k in (1, 3):
+                size = lib.nd_conv_weight_floats(N, C, k)
+                for v in range(-1, lib.nd_conv_num_variants()):
+                    r = lib.nd_conv_max_weight_read(v, N, C, k)
+                    assert 0 < r <= size, ('fp32', v, N, C, k, r, size)
+                size = lib.nd_conv_bf16_weight_elems(N, C, k)
+                for v in range(-1, lib.nd_conv_bf16_num_variants()):
+                    for splits in (1, 2, 3, 4, 8):
+                        r = lib.nd_conv_bf16_max_weight_read(v, N, C, k, splits)
+                        assert 0 < r <= size, ('bf16', v, N, C, k, splits, r, size)
+            size = lib.nd_conv_winograd_weight_floats(N, C)
+            for v in range(-1, lib.nd_conv_winograd_num_variants()):
+                r = lib.nd_conv_winograd_max_weight_read(v, N, C)
+                assert 0 < r <= size, ('wino', v, N, C, r, size)
+    # the bound is tight where it matters: the two-fragments-per-chunk 1x1 stream of the 16x16x32 layout needs both padding chunks
+    names = [lib.nd_conv_bf16_variant_name(v) for v in range(lib.nd_conv_bf16_num_variants())]
+    vs = [v for v, n in enumerate(names) if n == b'nd::conv_bf16s_kernel']
+    assert vs and any(lib.nd_conv_bf16_max_weight_read(v, 64, 128, 1, 1) == lib.nd_conv_bf16_weight_elems(64, 128, 1) for v in vs)
+    assert lib.nd_conv_max_weight_read(lib.nd_conv_num_variants(), 32, 32, 3) < 0 and lib.nd_conv_bf16_max_weight_read(0, 32, 32, 3, 0) < 0
+
+
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected on the host before any launch."""
     lib = _hip.load()
