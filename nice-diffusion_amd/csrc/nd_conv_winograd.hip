@@ -1538,6 +1538,9 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
+#if !defined(ND_EXPERIMENTAL_KERNELS)
+    ND_REQUIRE(kWinoCfg[variant][3] < 5 || kWinoCfg[variant][3] > 7, fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
+#endif
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
     const bool quad = kWinoCfg[variant][3] == 8;
     const bool wave16 = kWinoCfg[variant][3] == 7;

@@ -346,7 +346,8 @@ def test_conv_with_fused_groupnorm(silu):
                                             0, None, 0, out.data_ptr(), Cout, B, H, W, Cout, flags, v, cA.data_ptr(),
                                             cB.data_ptr(), C, st())
         if rc != 0:
-            assert 'one image per block' in _hip.last_error() or 'do not fold GroupNorm' in _hip.last_error()
+            assert 'one image per block' in _hip.last_error() or 'do not fold GroupNorm' in _hip.last_error() or \
+                'not built' in _hip.last_error()
             continue
         err = (from_nhwc(out, B, H, W, Cout) - ref3).abs().max().item()
         assert err < 3e-4, (v, err)
