@@ -36,6 +36,12 @@ PEAK_HBM_GBS = 8000.0
 # BASELINE.json configs.  The default (and the line the driver records) is configs[1]; --workload config4 / config5 run
 # the bf16 configurations at their per-GPU batch on one GPU (their lines are kept under profiles/).
 WORKLOADS = {
+    # BASELINE configs[0] (the reference's own CPU-runnable case, plumbing only): EMNIST preset model, 50-step DDIM, batch 4.
+    # The CPU side of this line is the oracle run IN FULL (3 repeats, median), not an extrapolation.
+    'config1': dict(preset='EMNIST', chain=50, ddim=True, sched='cosine', batch=4, dtype='fp32', cfg=None, classes=27,
+                    metric='sampled images/sec (50-step DDIM, EMNIST 28x28 UNet, batch 4)',
+                    name='EMNIST 28x28 UNet (EMNIST preset, 18M params), {}-step DDIM eta=0, cosine schedule, '
+                         'learned_interpolation, batch 4'),
     'config2': dict(preset='OPENAI_64', chain=250, ddim=True, sched='cosine', batch=64, dtype='fp32', cfg=None,
                     metric='sampled images/sec (250-step DDIM, 64x64 cond ImageNet UNet)',
                     name='64x64 conditional ImageNet UNet (OPENAI_64 preset, 296M params), {}-step DDIM eta=0, cosine '
@@ -108,13 +114,15 @@ def kernel_breakdown(model, batch, reps=2):
 
 
 def _traffic_table():
-    """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/r02_pmc_shapes.json:
+    """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/rNN_pmc_shapes.json:
     one entry per (kernel kind, variant, ksize, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
     inside this process, so the table is regenerated by that script and looked up by the shapes actually launched."""
-    try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_shapes.json')))
-    except (OSError, ValueError):
-        return None
+    for name in ('r03_pmc_shapes.json', 'r02_pmc_shapes.json'):
+        try:
+            return json.load(open(os.path.join(ROOT, 'profiles', name))), name
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
@@ -160,7 +168,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         kname = '{}<{}x{} tile, {} threads, {} taps>'.format(base, bm.value, bn.value, nt.value, ksize * ksize)
     # HBM traffic of this kernel over the forward: counter bytes of every shape it ran on / algorithmic bytes
     traffic = None
-    tab = _traffic_table()
+    tab, tab_name = _traffic_table()
     if tab:
         hb = ab = 0.0
         missing = 0
@@ -176,8 +184,8 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         if ab > 0:
             traffic = {'hbm_bytes_per_launch': hb / max(1, g['launches'] - missing), 'algorithmic_bytes_per_launch':
                        ab / max(1, g['launches'] - missing), 'ratio': round(hb / ab, 3), 'shapes_missing': missing,
-                       'source': 'profiles/r02_pmc_shapes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, keyed '
-                                 'by the shapes launched)'}
+                       'source': 'profiles/{} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, keyed by the shapes '
+                                 'launched)'.format(tab_name)}
     sec = g['ms'] * 1e-3
     achieved = g['exec'] / sec / 1e12
     total_ms = sum(r['ms'] for r in rows)
@@ -211,21 +219,39 @@ def class_breakdown(rows):
     return {k: round(v, 3) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
 
 
-def cpu_baseline(model, margs, wl, batch=None, steps=2):
+def cpu_baseline(model, margs, wl, batch=None, steps=1):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned against it in tests/) on this box's
-    host cores: `steps` sampler steps (UNet forward(s) + update) of the same workload at a small batch, extrapolated to
-    the whole chain."""
+    host cores.  configs[0] runs IN FULL (the whole 50-step chain at batch 4, 3 repeats, median).  The other workloads
+    take a bounded sample -- one untimed + ``steps`` timed sampler steps (UNet forward(s) + update) at a small batch --
+    extrapolated to the whole chain; it is a reported baseline, not a target."""
     from oracle import unet_oracle as UO, diffusion_oracle as DO
     R = margs['resolution']
-    if batch is None:
-        batch = 8 if R <= 64 else (2 if R <= 128 else 1)
+    ncls = wl.get('classes', 1000)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     so = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(sd, margs, a, b, c), DO.Schedule(1000, wl['chain'], wl['sched']),
                           'learned_interpolation', use_ddim=wl['ddim'], ddim_eta=0.0 if wl['ddim'] else None,
                           guidance_method=None if wl['cfg'] is None else 'classifier_free', guidance_strength=wl['cfg'])
+    if wl.get('preset') == 'EMNIST':
+        B = wl['batch']
+        torch.manual_seed(0)
+        x = torch.randn(B, margs.get('in_channels', 1), R, R)
+        y = (torch.arange(B) * 37) % ncls
+        so.denoise(x, y)                              # warm-up (thread pool, oneDNN primitive cache)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            so.denoise(x, y)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[1]
+        return {'value': round(B / med, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'host_cpus': os.cpu_count(), 'runs_s': [round(t, 3) for t in ts],
+                'sample': 'the whole workload: {}-step DDIM chain at batch {} on the host cores, 3 repeats, median {:.2f} s'
+                          .format(wl['chain'], B, med)}
+    if batch is None:
+        batch = 4 if R <= 64 else (2 if R <= 128 else 1)
     torch.manual_seed(0)
     x = torch.randn(batch, 3, R, R)
-    y = (torch.arange(batch) * 37) % 1000 + (1 if wl['cfg'] is not None else 0)
+    y = (torch.arange(batch) * 37) % ncls + (1 if wl['cfg'] is not None else 0)
     step = so.ddim_step if wl['ddim'] else so.ddpm_step
     t = wl['chain'] - 1
     x, _ = step(x, t, y)          # warm-up (thread pool, oneDNN primitive cache)
@@ -235,9 +261,10 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
     dt = (time.perf_counter() - t0) / steps
     return {'value': round(batch / (dt * wl['chain']), 6), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port', 'host_cpus': os.cpu_count(),
-            'sample': '{} sampler steps (UNet forward{} + update) at batch {} of the same {}x{} preset on the host cores, '
-                      '{:.2f} s/step, extrapolated x{} steps'.format(steps, 's (2 per step, CFG)' if wl['cfg'] is not None else '',
-                                                                     batch, R, R, dt, wl['chain'])}
+            'sample': '{} timed sampler step{} (UNet forward{} + update; one more untimed before) at batch {} of the same {}x{} '
+                      'preset on the host cores, {:.2f} s/step, extrapolated x{} steps'.format(
+                          steps, '' if steps == 1 else 's', 's (2 per step, CFG)' if wl['cfg'] is not None else '', batch, R, R, dt,
+                          wl['chain'])}
 
 
 def main():
@@ -310,8 +337,8 @@ def main():
     R = margs['resolution']
     # global batch generated identically on every rank, then sliced (an N-GPU run is comparable row by row)
     torch.manual_seed(0)
-    x_global = torch.randn(Bg, 3, R, R)
-    y_global = (torch.arange(Bg) * 37) % 1000 + (1 if wl['cfg'] is not None else 0)     # CFG: label 0 is the null class
+    x_global = torch.randn(Bg, margs.get('in_channels', 3), R, R)
+    y_global = (torch.arange(Bg) * 37) % wl.get('classes', 1000) + (1 if wl['cfg'] is not None else 0)   # CFG: label 0 is the null class
     from nicediffusion.parallel import shard_slice, all_gather_rows
     sl = shard_slice(Bg, rank, world)
     x_local = x_global[sl].to(device)
@@ -330,14 +357,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and not stub:
+        # rank 0 measures the tile variants, every rank runs its choices (identical kernels on every GPU)
+        from nicediffusion.parallel import tune_on_rank0
+        tune_on_rank0(model, (2 if wl['cfg'] is not None else 1) * B)
     for _ in range(args.warmup):
         one_pass()
     barrier()
+    # per-pass marks for the median: events on the launch stream, no synchronisation inside the timed region
+    marks = [] if stub else [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if marks:
+        marks[0].record()
+    for i in range(args.steps):
         out = one_pass()
+        if marks:
+            marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    pass_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -356,7 +394,7 @@ def main():
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if wl['dtype'] == 'fp32' else 'bf16',
-            'data': 'synthetic (random-init weights, randn x_T, labels (arange*37)%1000)',
+            'data': 'synthetic (random-init weights, randn x_T, labels (arange*37)%{})'.format(wl.get('classes', 1000)),
             'config': {'workload': wl['name'].format(args.chain), 'baseline_config': args.workload,
                        'per_gpu_batch': B, 'global_batch': Bg, 'sampler_steps_per_pass': args.chain,
                        'unet_forwards_per_sampler_step': fwd_per_step * B,
@@ -366,6 +404,12 @@ def main():
                        'loop': 'hipGraph replay' if diff.use_graph else 'eager'},
             'ms_per_sampler_step': round(ms_per_step / args.chain, 3),
         }
+        if pass_ms:
+            srt = sorted(pass_ms)
+            med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+            # `value` is the contract's mean over the timed region; the median of the passes (HIP events) is beside it
+            line['passes'] = {'ms': [round(v, 1) for v in pass_ms], 'median_ms': round(med, 2),
+                              'median_images_per_sec': round(Bg / (med * 1e-3) * (args.chain / full_chain), 4)}
         if wl['dtype'] == 'bf16':
             line['config']['precision'] = ('bf16 activations and weights in HBM, fp32 accumulation, fp32 GroupNorm statistics, '
                                            'fp32 embedding MLP and sampler state (tolerance vs the fp32 reference: DESIGN.md)')

@@ -47,6 +47,12 @@ def _load_tune_cache():
 def _save_tune_cache():
     path = _tune_cache_path()
     if path:
+        try:        # N ranks share the choices of rank 0 (parallel.tune_on_rank0): only that rank writes the file
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+                return
+        except ImportError:
+            pass
         json.dump({json.dumps(list(k)): list(v) for k, v in _TUNED.items()}, open(path, 'w'))
 
 

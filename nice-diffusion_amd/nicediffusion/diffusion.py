@@ -394,6 +394,10 @@ class Diffusion:
         if saved[0] is None:
             self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self.first_row = sl.start
+        model = getattr(self, 'model', None)
+        if model is not None and hasattr(model, '_plan') and getattr(self, 'device', torch.device('cpu')).type == 'cuda':
+            from .parallel import tune_on_rank0
+            tune_on_rank0(model, sl.stop - sl.start)            # every rank runs the kernels rank 0 measured fastest
         try:
             local = self.denoise(x=x[sl], kwargs=lk, batch_size=sl.stop - sl.start, noise=ln, **kw)
         finally:

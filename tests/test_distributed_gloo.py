@@ -104,3 +104,50 @@ def test_bench_multi_rank_branch_over_gloo():
     assert rec['config']['global_batch'] == 10 and rec['config']['per_gpu_batch'] == 5
     assert 'REHEARSAL' in rec['config']['parallelism'] and rec['vs_baseline'] is None
     assert abs(rec['value'] - 10 * 3 / (rec['ms_per_step'] * 3e-3)) / rec['value'] < 0.02      # whole-job images / MAX time
+
+
+def _tune_worker(rank, world, port, tmp, q):
+    sys.path.insert(0, os.path.join(ROOT, 'nice-diffusion_amd'))
+    import json
+    import torch.distributed as dist
+    from nicediffusion import _engine
+    from nicediffusion.parallel import share_tuned_choices
+    os.environ['ND_TUNE_CACHE'] = os.path.join(tmp, 'tune.json')
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+    try:
+        if rank == 0:       # what rank 0 measured on ITS device (ordinal 0)
+            _engine._TUNED[(0, 64, 64, 64, 192, 192, 3, 0, True, False)] = ('wino', 12)
+            _engine._TUNED[(0, 'bf16', 16, 8, 8, 1024, 1024, 3, 0, False, True, False, 'sk1', 'es1', 'gnnb')] = ('bf16+splitk', 19, 4)
+        else:               # a choice this rank already holds is kept
+            _engine._TUNED[(5, 64, 64, 64, 192, 192, 3, 0, True, False)] = ('wino', 8)
+        taken = share_tuned_choices(device_index=5 if rank else 0)
+        _engine._save_tune_cache()          # only rank 0 may write the shared file
+        dist.barrier()
+        q.put((rank, taken, sorted((list(map(str, k)), list(v)) for k, v in _engine._TUNED.items()),
+               json.load(open(os.environ['ND_TUNE_CACHE']))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_tuning_is_shared_and_only_rank0_writes_the_cache(tmp_path):
+    """parallel.share_tuned_choices: rank 0's measured kernel choices reach the other rank re-keyed to its device ordinal
+    (identical kernels on every rank => a sharded run is comparable bit for bit with the single-process one), an entry the
+    rank already holds is not overwritten, and ND_TUNE_CACHE is written by rank 0 alone."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, taken, tuned, cache = q.get(timeout=300)
+        got[r] = (taken, tuned, cache)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == 0 and got[1][0] == 1            # rank 1 took the bf16 choice, kept its own fp32 one
+    keys1 = {tuple(k): v for k, v in got[1][1]}
+    assert keys1[tuple(map(str, (5, 64, 64, 64, 192, 192, 3, 0, True, False)))] == ['wino', 8]
+    assert keys1[tuple(map(str, (5, 'bf16', 16, 8, 8, 1024, 1024, 3, 0, False, True, False, 'sk1', 'es1', 'gnnb')))] == ['bf16+splitk', 19, 4]
+    assert got[0][2] == got[1][2] and len(got[0][2]) == 2       # the file holds rank 0's two entries, whoever reads it

@@ -366,7 +366,9 @@ def test_sharded_denoise_two_ranks_one_gpu(tmp_path):
     y = (torch.arange(5) * 3) % 10
     single = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=5, progress=False).cpu()
     assert sharded.shape == single.shape
-    assert (sharded - single).abs().max().item() < 1e-5, (sharded - single).abs().max().item()
+    # bit for bit: every rank runs the kernel variants rank 0 chose (parallel.tune_on_rank0), every kernel family sums in
+    # an order that does not depend on the batch size, and the Philox stream is keyed by the element's GLOBAL index
+    assert torch.equal(sharded, single), (sharded - single).abs().max().item()
     # and the noise matters: a different seed moves the result by far more than that
     d.seed = 4243
     other = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=5, progress=False).cpu()
