@@ -560,7 +560,7 @@ def test_tiny_forward_bf16_vs_fp32_reference_golden(golden_dir, name):
     out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV), y).cpu().numpy()
     rms, mx = _errs(out, g['out'])
     print('bf16 forward {}: rel rms {:.2e}, max/absmax {:.2e}'.format(name, rms, mx))
-    assert rms < 3.5e-2 and mx < 8e-2, (rms, mx)
+    assert rms < TINY_FWD_BF16_BOUND[name][0] and mx < TINY_FWD_BF16_BOUND[name][1], (rms, mx)
     B = g['x'].shape[0]
     plan = m._plan(B)
     assert plan.bf16
@@ -568,7 +568,8 @@ def test_tiny_forward_bf16_vs_fp32_reference_golden(golden_dir, name):
     worst = {}
     for k in (k[4:] for k in g.files if k.startswith('tap/')):
         worst[k] = _errs(got[k].cpu().numpy(), g['tap/' + k])[0]
-    bad = {k: v for k, v in worst.items() if not v < 4e-2}
+    print('bf16 per-block worst rel rms {}: {:.2e}'.format(name, max(worst.values())))
+    bad = {k: v for k, v in worst.items() if not v < TAP_BF16_BOUND}
     assert not bad, bad
 
 
@@ -589,7 +590,7 @@ def test_preset_forward_bf16_vs_fp32(pname, B):
     assert np.isfinite(got).all()
     rms, mx = _errs(got, ref)
     print('bf16 forward preset {}: rel rms {:.2e}, max/absmax {:.2e}'.format(pname, rms, mx))
-    assert rms < 3.5e-2 and mx < 8e-2, (rms, mx)
+    assert rms < PRESET_FWD_BF16_BOUND[pname][0] and mx < PRESET_FWD_BF16_BOUND[pname][1], (rms, mx)
     again = m(x, t, y).cpu().numpy()
     assert np.array_equal(got, again)            # deterministic (no atomics on the path)
 
@@ -618,7 +619,88 @@ def test_teacher_forced_steps_bf16_vs_reference_trajectory(golden_dir):
             worst = max(worst, float(np.abs(got - traj[i]).max()))
             x = torch.from_numpy(traj[i])
         print('bf16 teacher-forced {}: max |x_(t-1) - reference| {:.2e}'.format(name, worst))
-        assert worst < 3e-2, (name, worst)
+        assert worst < TEACHER_FORCED_BF16_BOUND, (name, worst)
+
+
+# Measured drift of the FREE-RUNNING bf16 chains against the reference's fp32 trajectories (MI355X; printed by the tests below).
+# Every bound in this file is <= 2x what was measured, so a regression of the bf16 path shows up here, not only a broken kernel.
+# max |x_t - reference x_t| over the 10 steps; measured 0.037 / 0.037 / 0.028 / 0.023 / 0.0075 / 0.0066 / 0.015 / 0.011
+FREE_RUNNING_BF16_BOUND = {'ddim_cfg': 0.07, 'ddim_eta05_learned': 0.07, 'ddim_eta0_li': 0.055, 'ddpm_li': 0.045,
+                           'ddpm_learned': 0.015, 'ddpm_small': 0.013, 'ddpm_large': 0.03, 'ddpm_cfg': 0.021}
+# forward, relative rms / max over absmax against the reference's fp32 output; measured (rms, max):
+#   adagn_updown 1.55e-2, 1.67e-2 | plain_convres_legacy 1.51e-2, 2.81e-2 | pool_resample 1.38e-2, 1.57e-2 | odd_sizes 2.43e-2, 4.38e-2
+TINY_FWD_BF16_BOUND = {'adagn_updown': (3.0e-2, 3.3e-2), 'plain_convres_legacy': (3.0e-2, 5.6e-2), 'pool_resample': (2.7e-2, 3.1e-2),
+                       'odd_sizes': (4.8e-2, 8.0e-2)}
+#   EMNIST 1.50e-2, 1.67e-2 | OPENAI_64 1.00e-2, 1.14e-2 | OPENAI_128 1.06e-2, 1.31e-2 | OPENAI_256 8.8e-3, 9.6e-3
+PRESET_FWD_BF16_BOUND = {'EMNIST': (3.0e-2, 3.3e-2), 'OPENAI_64': (2.0e-2, 2.3e-2), 'OPENAI_128': (2.1e-2, 2.6e-2), 'OPENAI_256': (1.76e-2, 1.9e-2)}
+TAP_BF16_BOUND = 4e-2                     # per-block intermediates, relative rms; worst measured 1.42e-2 / 1.26e-2 / 1.39e-2 / 2.08e-2
+TEACHER_FORCED_BF16_BOUND = 1.2e-2        # measured 4.7e-3 / 6.1e-3 / 4.7e-3 (tiny models, 10 steps each)
+CONFIG1_STEP_BF16_BOUND = 1.35e-2        # measured 6.8e-3 (EMNIST preset, every 5th of the 50 DDIM steps, against the fp32 HIP trajectory)
+CONFIG4_STEP_BF16_BOUND = 3.0e-4          # measured 1.4e-4 / 1.3e-4 (128x128 DDPM + CFG step against the CPU oracle)
+
+
+@pytest.mark.parametrize('name', sorted(__import__('tests.cases', fromlist=['SAMPLER_CASES']).SAMPLER_CASES))
+def test_free_running_chain_bf16_vs_reference_trajectory(golden_dir, name):
+    """The eight committed 10-step sampler trajectories of the REFERENCE (contractive synthetic weights, the reference's own
+    noise draws; DDIM eta 0 / 0.5, DDPM x 4 variance types, classifier-free guidance) run FREE in bf16: every x_t feeds the
+    next step, nothing is teacher-forced (diffusion.py:215-220,266-369).  Checked along the whole trajectory."""
+    from tests.cases import SAMPLER_CASES
+    case = SAMPLER_CASES[name]
+    g = np.load(os.path.join(golden_dir, 'sampler_{}.npz'.format(name)))
+    cfg = dict(TINY_CFGS[case['cfg']])
+    learned = case['var'] in ('learned', 'learned_interpolation')
+    cfg['out_channels'] = cfg['in_channels'] * (2 if learned else 1)
+    m = build(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+    S = case['S']
+    d = Diffusion(m, 1000, S, case['var'], 'simple', beta_schedule=case['sched'], guidance_method=case.get('guidance'),
+                  guidance_strength=case.get('w'), use_ddim=case['ddim'], ddim_eta=case.get('eta'), device=torch.device(DEV))
+    y = torch.from_numpy(g['y']).to(DEV) if 'y' in g.files else None
+    kwargs = {'y': y} if y is not None else None
+    noises, traj, xT = torch.from_numpy(g['noises']), g['traj'], torch.from_numpy(g['xT'])
+    tr = []
+    out = d.denoise(x=xT, kwargs=kwargs, batch_size=xT.shape[0], progress=False, noise=noises, trace=tr)
+    got = torch.stack(tr).cpu().numpy()
+    per_step = np.abs(got - traj).reshape(S, -1).max(1)
+    rms, mx = _errs(got[-1], traj[-1])
+    print('bf16 free-running {}: max |x_t - reference| per step {}  final rel rms {:.2e} max/absmax {:.2e}'.format(
+        name, np.array2string(per_step, precision=4), rms, mx))
+    bound = FREE_RUNNING_BF16_BOUND[name]
+    assert per_step.max() < bound, (name, per_step.max(), bound)
+    d.use_graph = True
+    again = d.denoise(x=xT, kwargs=kwargs, batch_size=xT.shape[0], progress=False, noise=noises)
+    assert torch.equal(again, out)
+
+
+def test_config1_emnist_ddim50_bf16(golden_dir):
+    """BASELINE configs[0] (EMNIST preset, 50-step DDIM, batch 4) in bf16.  (a) Every 5th step teacher-forced from the fp32
+    HIP trajectory (which test_gpu_model pins to the reference's CPU output at 1e-3): x_{t-1} within 2x the measured
+    6.8e-3 of the fp32 step.  (b) The chain run FREE against the REFERENCE's output: with these synthetic, non-contractive
+    weights that per-step error grows to O(1) over 50 steps (measured: max 1.07, relative rms 0.34) -- stated, not hidden;
+    the bound only says the chain stays on the data range's scale."""
+    g = np.load(os.path.join(golden_dir, 'config1_emnist_ddim50.npz'))
+    kw = dict(beta_schedule='cosine', use_ddim=True, ddim_eta=0.0)
+    xT, y = torch.from_numpy(g['xT']), torch.from_numpy(g['y']).to(DEV)
+    m32 = build(dict(DA.EMNIST_MODEL_ARGS), dtype='fp32')
+    d32 = Diffusion(m32, 1000, 50, 'learned_interpolation', 'hybrid', device=torch.device(DEV), **kw)
+    tr = []
+    out32 = d32.denoise(x=xT, kwargs={'y': y}, batch_size=4, progress=False, trace=tr)
+    assert np.abs(out32.cpu().numpy() - g['out']).max() < 1e-3
+    m = build(dict(DA.EMNIST_MODEL_ARGS))
+    d = Diffusion(m, 1000, 50, 'learned_interpolation', 'hybrid', device=torch.device(DEV), **kw)
+    worst = 0.0
+    for i, t in enumerate(reversed(range(50))):
+        if i % 5 and i != 49:
+            continue
+        xt = xT if i == 0 else tr[i - 1].cpu()
+        got = d.denoise(x=xt, kwargs={'y': y}, batch_size=4, steps_to_do=1, first_index=t, progress=False)
+        worst = max(worst, float((got - tr[i]).abs().max()))
+    out = d.denoise(x=xT, kwargs={'y': y}, batch_size=4, progress=False).cpu().numpy()
+    err = float(np.abs(out - g['out']).max())
+    rms, mx = _errs(out, g['out'])
+    print('bf16 config[0]: teacher-forced step max err {:.2e}; 50-step free-running vs reference: max {:.2e}, rel rms {:.2e}'.format(
+        worst, err, rms))
+    assert worst < CONFIG1_STEP_BF16_BOUND, worst
+    assert np.isfinite(out).all() and rms < 0.7, (err, rms)
 
 
 def test_config4_workload_bf16_ddpm_cfg_128():
@@ -644,7 +726,7 @@ def test_config4_workload_bf16_ddpm_cfg_128():
         ref, _ = so.ddpm_step(x, t, y, nz)
         err = (got - ref).abs().max().item()
         print('bf16 config[3] teacher-forced step t={}: max err {:.2e}'.format(t, err))
-        assert err < 3e-2, (t, err)
+        assert err < CONFIG4_STEP_BF16_BOUND, (t, err)
         del noises
     B = 8
     xb = torch.randn(B, 3, 128, 128)
