@@ -126,7 +126,7 @@ def _traffic_table():
 
 
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
-            'nd_conv3x3_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc')
+            'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc')
 
 
 def roofline_from(rows, lib, dtype='fp32', esize=4):
@@ -215,6 +215,8 @@ def class_breakdown(rows):
         k = r['label'].split('.')[0] if r['fn'] not in CONV_FNS else r['label']
         if r['fn'].startswith('nd_groupnorm'):
             k = 'groupnorm_' + r['fn'].split('_')[2]
+            if r['fn'] == 'nd_groupnorm_channel_partials_nhwc':
+                k = 'groupnorm_stats'            # statistics = per-tensor channel partials + the folds into groups
         out[k] = out.get(k, 0.0) + r['ms']
     return {k: round(v, 3) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
 

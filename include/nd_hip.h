@@ -109,6 +109,15 @@ int nd_conv_winograd_num_variants(void);
  * equal N.  nd_groupnorm_stats_from_partials folds them into the per-group statistics of the next GroupNorm, which
  * therefore needs no pass over the tensor. */
 int nd_conv_winograd_stats_variant(void);
+/* The same for any variant that can (conv_wino16_kernel, conv_wino4_kernel): nd_conv_winograd_stats_rows gives the rows
+ * per image of chstats [NI][rows][sum | sum of squares][N] that variant writes (0: it cannot), every entry written by
+ * every launch; nd_groupnorm_stats_from_partials folds them. */
+int nd_conv_winograd_stats_rows(int variant, int NI, int H, int W);
+int nd_conv3x3_winograd_vstats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                    const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                    const float* residual, int ldr, float* out, int ldo,
+                                    int NI, int H, int W, int N, int flags, int variant,
+                                    float* chstats, nd_stream_t stream);
 int64_t nd_conv_winograd_stats_floats(int NI, int H, int W, int N, int* mbi);
 int nd_conv3x3_winograd_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                                    const float* w, const float* bias, const float* rowbias, int ld_rowbias,
@@ -219,6 +228,11 @@ int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, in
 /* Partial output statistics written by nd_conv3x3_winograd_stats_nhwc (p0: rows0 = mbi*4 partial rows per image over C0
  * channels; optionally concatenated with p1 over C1 channels) -> WRITES the per-group sums to stats [NI][1][G][2] (the
  * nblocks = 1 form of what nd_groupnorm_stats_nhwc fills), summed in a fixed order. */
+/* Per-channel partial sums of one tensor in the layout the convolutions' epilogues leave behind: rows
+ * [NI][nd_groupnorm_stats_blocks(NI, HW, C, dtype)][sum | sum of squares][C], fp32, every entry written.  A tensor's sums
+ * are computed once and re-grouped by every GroupNorm that reads it (alone or concatenated: model.py:474,190). */
+int nd_groupnorm_channel_partials_nhwc(const void* x, int C, int ldx, float* rows, int NI, int HW, int dtype,
+                                       nd_stream_t stream);
 int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
                                      double* stats, int NI, int G, nd_stream_t stream);
 /* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions

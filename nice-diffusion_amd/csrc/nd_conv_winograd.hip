@@ -1604,7 +1604,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     a.zero = w + (nd_conv_winograd_weight_floats(N, C0 + C1) - 256);     // inside the zero padding block
     a.chstats = chstats;
     a.mbi = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
-    if (chstats) ND_REQUIRE(variant == kStatsVariant && ldo == N, fn, "output statistics: only the position-split variant produces them (and needs ldo == N)");
+    if (chstats) ND_REQUIRE((variant == kStatsVariant || quad) && ldo == N, fn, "output statistics: only conv_wino16_kernel and conv_wino4_kernel produce them (and need ldo == N)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (variant) {
         case 0: return launch_wino<2, 1, false, 2>(a, grid, lds, s);
@@ -1660,6 +1660,28 @@ extern "C" int64_t nd_conv_winograd_stats_floats(int NI, int H, int W, int N, in
     const int m = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
     if (mbi) *mbi = m;
     return (int64_t)NI * m * 8 * N;
+}
+
+// rows per image of the partial statistics a variant's epilogue leaves behind ([NI][rows][sum | sum of squares][N], fp32):
+// conv_wino16_kernel one row per (m block, pixel-wave), conv_wino4_kernel one per m block; 0 = this variant cannot
+extern "C" int nd_conv_winograd_stats_rows(int variant, int NI, int H, int W) {
+    if (variant < 0 || variant >= kNumWino || NI <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return ND_E_ARG;
+    const bool quad = kWinoCfg[variant][3] == 8;
+    if (variant != kStatsVariant && !quad) return 0;
+    TilePlan best{};
+    if (!wino_tiles(1, 1, 208, NI, H, W, &best)) return 0;
+    const int m = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
+    return m * (quad ? 1 : 4);
+}
+
+extern "C" int nd_conv3x3_winograd_vstats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                               const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                               const float* residual, int ldr, float* out, int ldo,
+                                               int NI, int H, int W, int N, int flags, int variant,
+                                               float* chstats, nd_stream_t stream) {
+    if (!chstats) return fail_arg("nd_conv3x3_winograd_vstats_nhwc", "chstats is null");
+    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
+                       flags, variant, nullptr, nullptr, 0, chstats, stream);
 }
 
 extern "C" int nd_conv3x3_winograd_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,

@@ -62,6 +62,7 @@ __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
 #endif
 }
 
+template <bool STATS>          // STATS: also leave the per-channel partial statistics of the output behind (p.chstats)
 __global__ void __launch_bounds__(256, 2)
     conv_wino4_kernel(const ConvArgs p) {
     constexpr int BN = 64;
@@ -449,6 +450,12 @@ __global__ void __launch_bounds__(256, 2)
     const int txx = te & ((1 << twl2) - 1);
     const int img = img0 + li;
     __syncthreads();
+    f32x4 stat_s[2], stat_q[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        stat_s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stat_q[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int nb = n0 + n * 32 + 8 * xi + 4 * lh;          // first of this lane's 4 output channels
@@ -483,6 +490,7 @@ __global__ void __launch_bounds__(256, 2)
                         if (nb + c < p.N) rbv[c] = rbp[c];
                 }
             }
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};          // statistics of what this lane stores (p.chstats)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -509,6 +517,10 @@ __global__ void __launch_bounds__(256, 2)
                                 for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
                             }
                             *reinterpret_cast<f32x4*>(op) = yv;
+                            if constexpr (STATS) {
+                                ssum += yv;
+                                ssq += yv * yv;
+                            }
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
@@ -521,8 +533,59 @@ __global__ void __launch_bounds__(256, 2)
                                     if (rp) v2 += rp[c];
                                     if (p.silu_out) v2 = fast_silu(v2);
                                     op[c] = v2;
+                                    if constexpr (STATS) {
+                                        ssum[c] += v2;
+                                        ssq[c] += v2 * v2;
+                                    }
                                 }
                             }
+                        }
+                    }
+                }
+            }
+            stat_s[n] = ssum;
+            stat_q[n] = ssq;
+        }
+    }
+    if constexpr (STATS) {
+        // GroupNorm statistics of the output for free: per-channel sum / sum of squares over this block's pixels of each
+        // image (the tiles of one image are a power-of-two run of lanes), one row per (image, m block): chstats
+        // [NI][mbi][sum | sum of squares][N], plain stores, every entry written by every launch (no atomics).  Folded into
+        // any grouping by nd_groupnorm_stats_from_partials.
+        const int gl = 1 << (thl2 + twl2);          // tiles (= lanes of a half-wave) per image
+        const int mb = (p.nibl == 0) ? (ty * p.tiles_x + tx) : 0;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4 fin = stat_s[n], sq = stat_q[n];
+            bool writer;
+            if (gl == 32) {                             // DPP adds, no LDS traffic (nd_conv_common.h); total in lanes 16..31
+                sum8_over_32_lanes(fin, sq);
+                writer = l31 == 31;
+            } else if (gl == 16) {
+                sum8_over_16_lanes(fin, sq);
+                writer = (l31 & 15) == 0;
+            } else {
+                for (int m = 1; m < gl; m <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        fin[c] += __shfl_xor(fin[c], m);
+                        sq[c] += __shfl_xor(sq[c], m);
+                    }
+                }
+                writer = (l31 & (gl - 1)) == 0;
+            }
+            const int nb = n0 + n * 32 + 8 * xi + 4 * lh;
+            if (writer && img < p.NI && nb < p.N) {
+                float* ps = p.chstats + (((size_t)img * p.mbi + mb) * 2) * p.N + nb;
+                if (nb + 3 < p.N && (p.N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(ps) = fin;
+                    *reinterpret_cast<f32x4*>(ps + p.N) = sq;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (nb + c < p.N) {
+                            ps[c] = fin[c];
+                            ps[p.N + c] = sq[c];
                         }
                     }
                 }
@@ -543,9 +606,15 @@ __global__ void __launch_bounds__(256, 2)
 }
 
 int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set[kMaxDevices] = {};
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino4_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
-    hipLaunchKernelGGL(conv_wino4_kernel, dim3(grid), dim3(256), lds, s, a);
+    if (a.chstats) {
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino4_kernel<true>), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
+        hipLaunchKernelGGL(conv_wino4_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino4_kernel<false>), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
+        hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+    }
     return check_launch("nd_conv3x3_winograd_nhwc");
 }
 

@@ -73,10 +73,14 @@ __device__ __forceinline__ const T* gn_ptr(const GnSrc<T>& s, size_t pix, int c)
 }
 
 // grid: (pixel chunks, NI).  Threads are laid out as PY pixel rows x QX channel vectors.
-// partials: double [NI][gridDim.x][G][2], every entry written.
+// partials: double [NI][gridDim.x][G][2], every entry written.  With `chrows` the block's per-CHANNEL sums are written
+// instead, as fp32 rows [NI][gridDim.x][0|1][C] -- the same layout the convolutions' epilogues leave behind
+// (nd_conv3x3_winograd_vstats_nhwc), folded into groups by nd_groupnorm_stats_from_partials for ANY grouping: the sums
+// of a tensor are then computed once, where it is produced, and re-grouped by every norm that reads it (the up path's
+// concatenation norms, model.py:474,190, no longer re-read the skip tensors).
 template <typename T>
 __global__ void __launch_bounds__(GN_NT)
-    gn_stats_kernel(GnSrc<T> s, const float* addvec, int ld_add, double* partials, int HW,
+    gn_stats_kernel(GnSrc<T> s, const float* addvec, int ld_add, double* partials, float* chrows, int HW,
                     int G, int QX, int PY, int pix_per_block) {
     constexpr int V = GnVec<T>::N;
     extern __shared__ __attribute__((aligned(16))) double sh[];   // [PY][C][2], reused for [C][2] and the group sums
@@ -176,9 +180,17 @@ __global__ void __launch_bounds__(GN_NT)
         sh[c * 2 + 1] = b;
     }
     __syncthreads();
+    const int nchunks = gridDim.x;
+    if (chrows) {
+        float* row = chrows + ((size_t)img * nchunks + blockIdx.x) * 2 * C;
+        for (int c = tid; c < C; c += GN_NT) {
+            row[c] = (float)sh[c * 2];
+            row[C + c] = (float)sh[c * 2 + 1];
+        }
+        return;
+    }
     // fold the channels of every group in channel order; one partial per (block, group)
     const int cpg = C / G;
-    const int nchunks = gridDim.x;
     if (tid < G) {
         double a = 0.0, b = 0.0;
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
@@ -427,7 +439,7 @@ static void stats_geometry(int NI, int HW, int CQ, int* QX, int* PY, int* ppb, i
 
 template <typename T>
 static int launch_stats(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
-                        const float* addvec, int ld_add, double* partials, int NI, int HW, int G, hipStream_t st) {
+                        const float* addvec, int ld_add, double* partials, float* chrows, int NI, int HW, int G, hipStream_t st) {
     constexpr int V = GnVec<T>::N;
     const int C = C0 + C1, CQ = C / V;
     int QX, PY, ppb, chunks;
@@ -435,7 +447,7 @@ static int launch_stats(const char* fn, const void* x0, int C0, int ldx0, const 
     ND_REQUIRE(QX <= GN_NT, fn, "too many channels");
     GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
     const size_t lds = (size_t)PY * C * 2 * sizeof(double);
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, partials, HW, G, QX,
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, partials, chrows, HW, G, QX,
                        PY, ppb);
     return check_launch(fn);
 }
@@ -488,8 +500,22 @@ extern "C" int nd_groupnorm_stats_nhwc(const void* x0, int C0, int ldx0, const v
     ND_REQUIRE(partials != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ND_DT_BF16)
-        return launch_stats<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, NI, HW, G, st);
-    return launch_stats<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, NI, HW, G, st);
+        return launch_stats<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, nullptr, NI, HW, G, st);
+    return launch_stats<float>(fn, x0, C0, ldx0, x1, C1, ldx1, addvec, ld_add, partials, nullptr, NI, HW, G, st);
+}
+
+// Per-channel partial sums of ONE tensor: rows [NI][nd_groupnorm_stats_blocks(NI, HW, C, dtype)][sum | sum of squares][C]
+// in fp32 (each a float64 sum over the block's pixels, rounded once), every entry written by every launch.
+extern "C" int nd_groupnorm_channel_partials_nhwc(const void* x, int C, int ldx, float* rows, int NI, int HW, int dtype,
+                                                  nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_channel_partials_nhwc";
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    int rc = check_src(fn, x, C, ldx, nullptr, 0, 0, 1, dtype == ND_DT_BF16 ? 8 : 4);
+    if (rc) return rc;
+    ND_REQUIRE(rows != nullptr && NI > 0 && HW > 0, fn, "bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ND_DT_BF16) return launch_stats<__bf16>(fn, x, C, ldx, nullptr, 0, 0, nullptr, 0, nullptr, rows, NI, HW, 1, st);
+    return launch_stats<float>(fn, x, C, ldx, nullptr, 0, 0, nullptr, 0, nullptr, rows, NI, HW, 1, st);
 }
 
 extern "C" int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,

@@ -85,12 +85,22 @@ class Normed:
             setattr(self, k, v)
 
 
-def _epilogue_stats_enabled():
-    """ND_GN_EPILOGUE_STATS=1: let the position-split Winograd convs leave partial GroupNorm statistics of their output
-    behind (nd_conv3x3_winograd_stats_nhwc + nd_groupnorm_stats_from_partials) instead of a statistics pass over the
-    tensor.  Off by default: measured at B=64 it removes 1.0 ms of HBM-bound statistics kernels but the cross-lane
-    reduction in the epilogue costs the MFMA-bound convs 2.2 ms (forward 76.8 vs 75.6 ms)."""
-    return os.environ.get('ND_GN_EPILOGUE_STATS', '0') == '1'
+def _epilogue_stats_mode():
+    """ND_GN_EPILOGUE_STATS: which fp32 Winograd convs leave the per-channel partial statistics of their output behind for
+    the GroupNorms that read it (nd_conv3x3_winograd_vstats_nhwc + nd_groupnorm_stats_from_partials) instead of a statistics
+    pass over the tensor.  'auto' (default): conv_wino4_kernel only, whose epilogue pays ~90 vector instructions per
+    n tile for it; '1': conv_wino16_kernel too (measured at B=64: removes 1.0 ms of statistics kernels, costs the
+    MFMA-bound convs 2.2 ms -- on these fp32 kernels every vector instruction takes its cycles from the matrix pipe);
+    '0': never."""
+    return os.environ.get('ND_GN_EPILOGUE_STATS', 'auto')
+
+
+def _gn_partials_enabled():
+    """ND_GN_PARTIALS=0 restores one statistics pass over the (concatenated) input of every GroupNorm.  Default: every
+    tensor's per-channel sums are computed ONCE -- by the epilogue of the conv that produces it, or by one
+    nd_groupnorm_channel_partials_nhwc pass over that tensor alone -- kept with the activation and re-grouped by every
+    norm that reads it, so the up path's concatenation norms (model.py:474,190) no longer re-read the skip tensors."""
+    return os.environ.get('ND_GN_PARTIALS', '1') != '0'
 
 
 def _bf16_epilogue_stats():
@@ -295,16 +305,17 @@ class UNetPlan:
             wq = self._packed_wino(weight, pad_c_to)
             self.keep.append(wq)
             self.packed_floats += wq.numel()
-            if (want_stats and _epilogue_stats_enabled() and var == self.lib.nd_conv_winograd_stats_variant()
-                    and gn[0] is None and out.ld == N):
-                # the position-split kernel leaves the next GroupNorm's statistics behind (no extra pass over `out`)
-                mbi = ctypes.c_int()
-                nfl = self.lib.nd_conv_winograd_stats_floats(NI, H, W, N, ctypes.byref(mbi))
-                assert nfl > 0
+            mode = _epilogue_stats_mode()
+            rows = 0
+            if want_stats and mode != '0' and gn[0] is None and out.ld == N and (
+                    mode == '1' or self.lib.nd_conv_winograd_variant_name(var) == b'nd::conv_wino4_kernel'):
+                rows = self.lib.nd_conv_winograd_stats_rows(var, NI, H, W)
+            if rows > 0:
+                # the conv leaves the per-channel partial statistics of its output behind (no pass over `out` for any norm)
                 ph = ('chpart', self._cs_floats)
-                out.cs = (ph, mbi.value * 4)
-                self._cs_floats += (nfl + 3) // 4 * 4
-                self._emit(self.lib.nd_conv3x3_winograd_stats_nhwc, head + [wq.data_ptr()] + tail + [flags, ph], label,
+                out.cs = (ph, rows)
+                self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
+                self._emit(self.lib.nd_conv3x3_winograd_vstats_nhwc, head + [wq.data_ptr()] + tail + [flags, var, ph], label,
                            flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
             else:
                 self._emit(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, var] + gn, label,
@@ -638,6 +649,19 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
+        if _gn_partials_enabled():
+            # every source that does not carry per-channel partial sums yet gets them from ONE pass over that tensor alone;
+            # they stay with the activation (skip tensors are normalised again in the up path, concatenated: no re-read)
+            for a in (src, src2):
+                if a is not None and a.cs is None and a.C % (8 if self.bf16 else 4) == 0 and a.ld % (8 if self.bf16 else 4) == 0:
+                    nb = self.lib.nd_groupnorm_stats_blocks(NI, H * W, a.C, self.dt)
+                    if nb <= 0:
+                        continue
+                    ph = ('chpart', self._cs_floats)
+                    self._cs_floats += (NI * nb * 2 * a.C + 3) // 4 * 4
+                    self._emit(self.lib.nd_groupnorm_channel_partials_nhwc, [a.ptr, a.C, a.ld, ph, NI, H * W, self.dt],
+                               label + '.channel_partials')
+                    a.cs = (ph, nb)
         from_conv = src.cs is not None and (src2 is None or src2.cs is not None)
         nblk = 1 if from_conv else self.lib.nd_groupnorm_stats_blocks(NI, H * W, C, self.dt)
         assert nblk > 0

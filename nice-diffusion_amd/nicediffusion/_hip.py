@@ -41,6 +41,9 @@ SIGNATURES = {
     'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     'nd_conv3x3_winograd_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                        _i, _i, _i, _i, _i, _vp, _vp],
+    'nd_conv3x3_winograd_vstats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                        _i, _i, _i, _i, _i, _i, _vp, _vp],
+    'nd_groupnorm_channel_partials_nhwc': [_vp, _i, _i, _vp, _i, _i, _i, _vp],
     'nd_groupnorm_coeffs': [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -89,6 +92,7 @@ _SPECIAL = {
     'nd_conv_winograd_max_weight_read': ([_i, _i, _i], _i64),
     'nd_conv_winograd_num_variants': ([], _i),
     'nd_conv_winograd_stats_variant': ([], _i),
+    'nd_conv_winograd_stats_rows': ([_i, _i, _i, _i], _i),
     'nd_conv_winograd_stats_floats': ([_i, _i, _i, _i, ctypes.POINTER(_i)], _i64),
     'nd_conv_winograd_variant_info': ([_i] + [ctypes.POINTER(_i)] * 5, _i),
     'nd_conv_winograd_variant_name': ([_i], ctypes.c_char_p),

@@ -318,9 +318,12 @@ def test_one_captured_graph_serves_every_seed():
     assert torch.equal(c1, c2) and torch.equal(c1, c3)
 
 
-def test_epilogue_statistics_option_matches_default(monkeypatch):
-    """ND_GN_EPILOGUE_STATS=1 (GroupNorm statistics from the conv epilogue instead of a pass over the tensor) gives the
-    same forward as the default plan, on a model large enough for the autotuner to pick the position-split kernel."""
+def test_groupnorm_statistics_routes_agree(monkeypatch):
+    """Three ways to the same GroupNorm statistics give the same forward, on a model large enough for the autotuner to pick
+    the Winograd kernels: (a) ND_GN_PARTIALS=0 + ND_GN_EPILOGUE_STATS=0: one float64 pass over every norm's (concatenated)
+    input; (b) the default: per-channel partial sums computed once per tensor -- by the epilogue of conv_wino4_kernel or
+    by one pass over that tensor -- and re-grouped by every norm that reads it; (c) ND_GN_EPILOGUE_STATS=1:
+    conv_wino16_kernel's epilogue too."""
     cfg = dict(resolution=32, in_channels=3, model_channels=96, out_channels=6, num_res_blocks=1, attention_resolutions=(16,),
                channel_mult=(1, 2), num_head_channels=32, num_classes=10, use_adaptive_gn=True, resblock_updown=True,
                split_qkv_first=True)
@@ -332,16 +335,34 @@ def test_epilogue_statistics_option_matches_default(monkeypatch):
             if p_.abs().max() == 0:
                 p_.normal_(0, 0.02)
     x, t, y = torch.randn(16, 3, 32, 32, device=DEV), torch.full((16,), 321, device=DEV), torch.arange(16, device=DEV) % 10
-    a = m(x, t, y).clone()
-    monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '1')
+
+    def names():
+        return [f.__name__ for f, _, _ in m._plan(16).ops]
+    monkeypatch.setenv('ND_GN_PARTIALS', '0')
+    monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '0')
     m._plans = {}
-    b = m(x, t, y).clone()
-    plan = m._plan(16)
-    used = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_conv3x3_winograd_stats_nhwc')
+    a = m(x, t, y).clone()
+    na = names()
+    assert 'nd_groupnorm_stats_from_partials' not in na and 'nd_groupnorm_stats_nhwc' in na
+    monkeypatch.delenv('ND_GN_PARTIALS')
     monkeypatch.delenv('ND_GN_EPILOGUE_STATS')
     m._plans = {}
-    assert torch.isfinite(b).all() and (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
-    assert used > 0, 'the option did not engage (the tuner chose other kernels for every conv)'
+    b = m(x, t, y).clone()
+    nb = names()
+    # every norm folds partial rows; a tensor is passed over at most once (fewer passes than norms: skip tensors are re-used)
+    assert 'nd_groupnorm_stats_nhwc' not in nb and nb.count('nd_groupnorm_stats_from_partials') == na.count('nd_groupnorm_stats_nhwc')
+    assert nb.count('nd_groupnorm_channel_partials_nhwc') < na.count('nd_groupnorm_stats_nhwc')
+    monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '1')
+    m._plans = {}
+    c = m(x, t, y).clone()
+    nc = names()
+    monkeypatch.delenv('ND_GN_EPILOGUE_STATS')
+    m._plans = {}
+    tol = 2e-5 * max(1.0, a.abs().max().item())
+    assert torch.isfinite(b).all() and (a - b).abs().max().item() < tol and (a - c).abs().max().item() < tol
+    assert 'nd_conv3x3_winograd_vstats_nhwc' in nc, 'no conv left statistics behind (the tuner chose other kernels for every conv)'
+    b2 = m(x, t, y)
+    assert torch.equal(b, b2)          # and the default route is bitwise repeatable (no atomics anywhere)
 
 
 def test_sharded_denoise_two_ranks_one_gpu(tmp_path):

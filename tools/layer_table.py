@@ -12,7 +12,7 @@ tot = sum(r['ms'] for r in rows)
 print('forward %.2f ms, %.1f TFLOP/s' % (tot, plan.flops / tot / 1e9))
 agg = {}
 for r in rows:
-    if r['fn'] in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc') and r['shape']:
+    if r['fn'] in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv3x3_winograd_vstats_nhwc') and r['shape']:
         k = (r['ksize'],) + tuple(r['shape']) + (r['variant'],)
         a = agg.setdefault(k, [0, 0.0, 0])
         a[0] += 1; a[1] += r['ms']; a[2] += r['flops']
@@ -21,6 +21,6 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%-4d %-26s %-10s %5d %9.3f %8.3f %7.1f' % (k[0], ','.join(map(str, k[1:6])), '%s%d' % (k[6][0][0], k[6][1]), a[0], a[1], a[1] / a[0], a[2] / a[1] / 1e9))
 oth = {}
 for r in rows:
-    if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc'):
+    if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv3x3_winograd_vstats_nhwc'):
         oth[r['fn']] = oth.get(r['fn'], 0) + r['ms']
 print({k: round(v, 3) for k, v in oth.items()})
