@@ -136,6 +136,8 @@ constexpr int kWino4HaloPixels = kWino4HaloRounds * 4 * 64 / 8;      // 224 >= t
 int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
 // gemm_f32_kernel (nd_gemm_f32.hip), launched by nd_conv_nhwc's variant 13
 int launch_gemm_f32(const ConvArgs& a, int grid, hipStream_t s);
+// gemm4_kernel (nd_gemm_f32_quad.hip), launched by nd_conv_nhwc's variant 14
+int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s);
 
 static inline int ilog2(int v) {
     int l = 0;

@@ -637,6 +637,9 @@ static const Variant kVariants[] = {
     {4, 1, 2, 3, 2},   // 12: 256 x  96
     // GEMM form (gemm_f32_kernel, nd_gemm_f32.hip): both operands through three LDS stages filled by LDS-DMA
     {4, 2, 2, 2, 1},   // 13: 256 x 128, 8 waves
+    // GEMM form, two blocks per CU (gemm4_kernel, nd_gemm_f32_quad.hip): pixel rows by buffer_load lds, no vector
+    // instruction per DMA, hand-counted waits
+    {2, 2, 4, 2, 2},   // 14: 256 x 128, 4 waves
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr int kFirstStream = 9;
@@ -771,7 +774,8 @@ extern "C" int64_t nd_conv_max_weight_read(int variant, int N, int C, int ksize)
     int ahead = 0;
     for (int v = 0; v < kNumVariants; ++v) {
         if (variant >= 0 && v != variant) continue;
-        const int a = v < kFirstStream ? wstream::f32_conv_ahead(taps) : (v < 13 ? wstream::kF32StreamAhead : wstream::kF32GemmAhead);
+        const int a = v < kFirstStream ? wstream::f32_conv_ahead(taps)
+                                       : (v < 13 ? wstream::kF32StreamAhead : (v == 13 ? wstream::kF32GemmAhead : wstream::kF32Gemm4Ahead));
         ahead = a > ahead ? a : ahead;
     }
     return (int64_t)(nc32_padded(C) + wstream::pad_chunks(ahead, taps * 4)) * nt32 * taps * 4 * 256;
@@ -873,6 +877,13 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
         case 13:
             a.zero = w + (nd_conv_weight_floats(N, C0 + C1, ksize) - 4);      // 16 bytes of the packed weights' zero padding chunk
             return launch_gemm_f32(a, grid, s);
+        case 14:
+            // gemm4_kernel addresses its input through buffer descriptors with the row advance in the scalar offset
+            ND_REQUIRE(M % 256 == 0, fn, "the two-blocks-per-CU GEMM needs a multiple of 256 pixels");
+            ND_REQUIRE(((C0 + C1) & 31) == 0 && (C1 == 0 || (C0 & 31) == 0), fn, "the two-blocks-per-CU GEMM needs whole 32-channel chunks");
+            ND_REQUIRE(M * ldx0 * 4 < (1L << 31) && (C1 == 0 || M * ldx1 * 4 < (1L << 31)), fn,
+                       "the two-blocks-per-CU GEMM needs input tensors of less than 2 GiB");
+            return launch_gemm4(a, grid, s);
     }
     return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
 }

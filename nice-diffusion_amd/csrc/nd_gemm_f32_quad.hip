@@ -1,0 +1,271 @@
+// K6, GEMM-shaped fp32 1x1 convolution, two blocks per CU (variant 14 of nd_conv_nhwc; flat pixel lists only):
+//   out[M][N] = x[M][K] . w[N][K]^T  (+ bias, + residual, GroupNorm of x folded in) -- the qkv / proj / skip convolutions
+//   of the attention and residual blocks (reference: nicediffusion/model.py:247-253,266-287,169-170,182).
+//
+// Built on what conv_wino4_kernel (nd_conv_winograd_quad.hip) established for fp32 MFMA kernels on gfx950:
+//   * every vector instruction issued on a SIMD takes its cycles from the matrix pipe, so the main loop carries ONE
+//     v_xor per k-step (32 MFMAs): pixel rows arrive by buffer_load ... lds with the row advance in the scalar offset
+//     (8 DMAs per wave and chunk, no address arithmetic), the four pixel fragments of a k-step are one address + immediate
+//     offsets, weight fragments come from a scalar base + a constant lane offset;
+//   * 4 waves at <= 256 registers, 64 KiB of LDS: two blocks per CU, one covers the other's prologue / epilogue / waits;
+//   * operand loads are inline ISA with hand-counted vmcnt / lgkmcnt (hipcc parks every LDS read behind all pending
+//     LDS-DMA otherwise), everything for k-step s + 1 is requested at the top of k-step s.
+// Block = 256 pixels x 128 channels (2 x 2 waves, wave tile 4 x 2 MFMA tiles = 8 accumulators), K in 32-channel chunks
+// through two LDS stages at 0 and 32 KiB (the stage is one address bit).  The host requires M % 256 == 0, whole
+// 32-channel chunks on either side of a concatenation seam and tensors < 2 GiB (32-bit buffer offsets); with a fused
+// GroupNorm also H * W % 256 == 0 (one image per block).
+#include "nd_conv_common.h"
+
+namespace nd {
+
+template <bool GN>
+__global__ void __launch_bounds__(256, 2)
+    gemm4_kernel(const ConvArgs p) {
+    constexpr int BM = 256, BN = 128, TM = 4, TN = 2;
+    constexpr int STAGE_B = 32768;                     // bytes between the two stages (a stage holds 256 rows x 128 bytes)
+    constexpr int NDMA = 8;                            // DMA rounds per wave and chunk: 8 x 4 waves x 1 KiB = 32 KiB
+    constexpr int LPS = GN ? 4 : 2;                    // register loads per k-step: 2 weight fragments (+ 2 coefficient vectors)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    __builtin_amdgcn_s_setprio(3);                     // prologue / epilogue: vector + memory streams, the other block has the MFMAs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
+    const int M = p.W;                                 // flat pixel list
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int nchunks = p.NC32;
+
+    // ---- pixel-row DMAs.  Round k of this wave fills rows (k * 4 + wave) * 8 + lane / 8 of the stage; lane % 8 is the
+    //      PHYSICAL 16-byte slot, which holds logical channel slot (lane % 8) ^ swz(row), swz(row) = (row >> 1) & 7 -- the
+    //      same for every round (a round is 32 rows further).  So ONE byte offset per lane and source, and round / chunk
+    //      live in the scalar offset: no vector instruction per DMA.
+    const int row8 = wave * 8 + (lane >> 3);
+    const int lslot = (lane & 7) ^ ((row8 >> 1) & 7);
+    const unsigned vo0 = __umul24((unsigned)row8, (unsigned)p.ldx0 * 4u) + (unsigned)(lslot << 4);
+    const unsigned vo1 = __umul24((unsigned)row8, (unsigned)p.ldx1 * 4u) + (unsigned)(lslot << 4);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x0), 0, (int)((unsigned)M * (unsigned)p.ldx0 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, (int)((unsigned)M * (unsigned)p.ldx1 * 4u), 0x00020000);
+    // chunks past the last one re-fetch the last chunk into a stage nobody reads: the number of VMEM operations per chunk
+    // is a constant the hand-counted waits rely on
+    auto dma = [&](int k, int ch, int stage) {
+        const int che = ch < nchunks - 1 ? ch : nchunks - 1;
+        const int c0 = che * 32;
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + stage * (STAGE_B / 4) + (k * 4 + wave) * 256);
+        if (c0 < p.C0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)vo0, (m0 + k * 32) * p.ldx0 * 4 + c0 * 4, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, (int)vo1, (m0 + k * 32) * p.ldx1 * 4 + (c0 - p.C0) * 4, 0, 0);
+    };
+
+    // ---- fragment reads: row = (wm * 4 + mi) * 32 + l31 (same swizzle for the four mi), slot (kc << 1 | lh) ^ swz
+    const int arow = wm * 128 + l31;
+    const int aoff = arow * 128 + ((lh ^ ((arow >> 1) & 7)) << 4);          // bytes, k-step 0, stage 0; mi adds 4096 per tile
+    auto rdA = [&](f32x4 (&a)[TM], int sbits) {          // sbits = stage bit | (kc << 5): one v_xor, four reads
+        const int addr = aoff ^ sbits;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(addr));
+    };
+    // ---- weight fragments [c32][n tile][kc][lane][4]: scalar base + lane * 16; the wave's two n tiles are 4 KiB apart
+    int nt0 = nblk * 4 + wn * 2, nt1 = nt0 + 1;
+    nt0 = nt0 > p.NT32 - 1 ? p.NT32 - 1 : nt0;          // N tail: clamped, results dropped in the epilogue
+    nt1 = nt1 > p.NT32 - 1 ? p.NT32 - 1 : nt1;
+    const float* bw0 = p.w + (size_t)nt0 * 1024;
+    const float* bw1 = p.w + (size_t)nt1 * 1024;
+    const size_t c32_stride = (size_t)p.NT32 * 1024;
+    const int voff = lane * 16;
+    static_assert(wstream::pad_chunks(wstream::kF32Gemm4Ahead, 4) <= wstream::kF32PadChunks, "weight read-ahead exceeds the packer's zero padding");
+    auto ldB = [&](f32x4 (&b)[TN], size_t foff, int kc) {          // foff: float offset of the chunk
+        const float* s0 = bw0 + foff;
+        const float* s1 = bw1 + foff;
+        switch (kc) {
+            case 0: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(voff), "s"(s0));
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[1]) : "v"(voff), "s"(s1)); break;
+            case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[0]) : "v"(voff), "s"(s0));
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(voff), "s"(s1)); break;
+            case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[0]) : "v"(voff), "s"(s0));
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(b[1]) : "v"(voff), "s"(s1)); break;
+            default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(b[0]) : "v"(voff), "s"(s0));
+                     asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(b[1]) : "v"(voff), "s"(s1)); break;
+        }
+    };
+    // ---- fused GroupNorm: x' = act(x * A[img][c] + B[img][c]); this block's image, channels 8 kc + 4 lh .. + 3 of the chunk
+    const float* ga = nullptr;
+    const float* gb = nullptr;
+    const int goff = lh * 16;
+    if constexpr (GN) {
+        const int gimg = m0 / p.gn_hw;
+        ga = p.gnA + (size_t)gimg * p.ld_gn;
+        gb = p.gnB + (size_t)gimg * p.ld_gn;
+    }
+    auto ldC = [&](f32x4 (&c)[2], int ch, int kc) {
+        if constexpr (GN) {
+            const int che = ch < nchunks - 1 ? ch : nchunks - 1;         // (the run-ahead past the last chunk stays inside the row)
+            const float* sa = ga + che * 32 + kc * 8;
+            const float* sb = gb + che * 32 + kc * 8;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c[0]) : "v"(goff), "s"(sa));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c[1]) : "v"(goff), "s"(sb));
+        }
+    };
+    auto wait_vm = [&](f32x4 (&b)[TN], f32x4 (&c)[2], int n) {
+#define ND_G4CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1])); break;
+        switch (n) {
+            ND_G4CASE(2) ND_G4CASE(4) ND_G4CASE(10) ND_G4CASE(12)
+            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1])); break;
+        }
+#undef ND_G4CASE
+    };
+    auto wait_lds4 = [&](f32x4 (&a)[TM]) {          // the four reads of THIS k-step have returned; the four just issued may be in flight
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    f32x4 afr[2][TM], bfr[2][TN], cfr[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cfr[i][0] = cfr[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue.  VMEM order: chunk 0's rows, the operands of k-step 0, chunk 1's rows (the order the loop leaves behind)
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dma(k, 0, 0);
+    ldB(bfr[0], 0, 0);
+    ldC(cfr[0], 0, 0);
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dma(k, 1, 1);
+    if constexpr (GN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // chunk 0 has landed: LPS + 8 younger operations
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rdA(afr[0], 0);
+    __builtin_amdgcn_s_setprio(0);
+
+#define ND_SB __builtin_amdgcn_sched_barrier(0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int sb = (ch & 1) * STAGE_B, sn = ((ch + 1) & 1) * STAGE_B;
+        const size_t fq = (size_t)ch * c32_stride;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            // ---- everything k-step st + 1 needs is requested now (it has this k-step's 32 MFMAs to arrive): pixel fragments
+            //      from this chunk's stage or -- behind the barrier of k-step 2 -- the next chunk's, weights one k-step on
+            //      (the stream ends in a zero chunk), coefficients
+            int sbits = ((st < 3) ? sb : sn) | (((st + 1) & 3) << 5);
+            asm volatile("" : "+s"(sbits));
+            rdA(afr[nxt], sbits);
+            if (st < 3) { ldB(bfr[nxt], fq, st + 1); ldC(cfr[nxt], ch, st + 1); }
+            else { ldB(bfr[nxt], fq + c32_stride, 0); ldC(cfr[nxt], ch + 1, 0); }
+            // this k-step's operands: issued one k-step ago; younger = the LPS loads above (+ the 8 DMAs of k-step 3)
+            wait_vm(bfr[cur], cfr[cur], LPS + (st == 0 ? NDMA : 0));
+            wait_lds4(afr[cur]);
+            ND_SB;
+            const int dstage = ch & 1;          // behind the barrier of k-step 2 this chunk's stage is free for chunk ch + 2
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                if constexpr (GN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = afr[cur][mi][e] * cfr[cur][0][e] + cfr[cur][1][e];
+                        if (p.gn_silu) v = fast_silu(v);
+                        afr[cur][mi][e] = v;
+                    }
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][ni][j], afr[cur][mi][j], acc[mi][ni], 0, 0, 0);
+                        if (st == 3 && j == 1) dma(mi * 2 + ni, ch + 2, dstage);          // 8 rounds over the k-step's 32 MFMAs
+                        ND_SB;
+                    }
+                }
+            }
+            if (st == 2) {
+                // every read of this chunk's stage has returned (k-step 3's were waited for above), chunk ch + 1 landed long
+                // ago (k-step 1's vmcnt(LPS) left nothing older than its own loads in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+#undef ND_SB
+    // the run-ahead loads of the last k-step are still in flight: keep their registers allocated until they have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(cfr[0][0]), "+v"(cfr[0][1]),
+                   "+v"(cfr[1][0]), "+v"(cfr[1][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3]),
+                   "+v"(afr[1][0]), "+v"(afr[1][1]), "+v"(afr[1][2]), "+v"(afr[1][3])
+                 :
+                 : "memory");
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
+    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + l31;
+        if (m < M) {
+            const size_t opix = (size_t)m;
+            const float* rr = p.res ? p.res + opix * p.ldr : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                    if (n + 3 < p.N && vec_ok) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
+                                   acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rr) v += *reinterpret_cast<const f32x4*>(rr + n);
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + n) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = acc[mi][ni][4 * g4 + e];
+                                if (p.bias) v += p.bias[n + e];
+                                if (rr) v += rr[n + e];
+                                if (p.silu_out) v = fast_silu(v);
+                                p.out[opix * p.ldo + n + e] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)64 * 1024;
+    if (a.gnA) {
+        auto kern = gemm4_kernel<true>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        auto kern = gemm4_kernel<false>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    }
+    return check_launch("nd_conv_nhwc");
+}
+
+}  // namespace nd

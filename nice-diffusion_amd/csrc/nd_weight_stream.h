@@ -22,6 +22,7 @@ constexpr int kF32PadChunks = 1;
 constexpr int f32_conv_ahead(int taps) { return taps == 9 ? 1 : 3; }      // conv_mfma_kernel's BDIST
 constexpr int kF32StreamAhead = 3;                                         // gemm_stream_kernel's D
 constexpr int kF32GemmAhead = 0;                                           // gemm_f32_kernel: stages are only issued for real chunks
+constexpr int kF32Gemm4Ahead = 1;                                          // gemm4_kernel: one k-step
 
 // ---- Winograd forms (nd_conv_winograd_weight_floats): chunk = 32 channels, 4 k-steps of 16 positions per chunk and n tile
 constexpr int kWinoPadChunks = 1;
