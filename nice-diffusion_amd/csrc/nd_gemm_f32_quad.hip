@@ -116,13 +116,24 @@ __global__ void __launch_bounds__(256, 2)
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c[1]) : "v"(goff), "s"(sb));
         }
     };
-    auto wait_vm = [&](f32x4 (&b)[TN], f32x4 (&c)[2], int n) {
-#define ND_G4CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1])); break;
+    auto wait_vm = [&](f32x4& r0, f32x4& r1, int n) {
+#define ND_G4CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(r0), "+v"(r1)); break;
         switch (n) {
-            ND_G4CASE(2) ND_G4CASE(4) ND_G4CASE(10) ND_G4CASE(12)
-            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1])); break;
+            ND_G4CASE(2) ND_G4CASE(4) ND_G4CASE(6) ND_G4CASE(10) ND_G4CASE(12)
+            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)); break;
         }
 #undef ND_G4CASE
+    };
+    // GroupNorm of one pixel fragment, in place (the SiLU choice is made once per call, outside the element loop)
+    auto fold = [&](f32x4& a, const f32x4 (&c)[2]) {
+        if constexpr (GN) {
+            f32x4 v = a * c[0] + c[1];
+            if (p.gn_silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+            }
+            a = v;
+        }
     };
     auto wait_lds4 = [&](f32x4 (&a)[TM]) {          // the four reads of THIS k-step have returned; the four just issued may be in flight
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
@@ -143,14 +154,20 @@ __global__ void __launch_bounds__(256, 2)
     // ---- prologue.  VMEM order: chunk 0's rows, the operands of k-step 0, chunk 1's rows (the order the loop leaves behind)
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) dma(k, 0, 0);
-    ldB(bfr[0], 0, 0);
     ldC(cfr[0], 0, 0);
+    ldB(bfr[0], 0, 0);
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) dma(k, 1, 1);
     if constexpr (GN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // chunk 0 has landed: LPS + 8 younger operations
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     rdA(afr[0], 0);
+    if constexpr (GN) {
+        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)"          // the coefficients of k-step 0: 2 weight loads + 8 DMA rounds are younger
+                     : "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3]), "+v"(cfr[0][0]), "+v"(cfr[0][1]));
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) fold(afr[0][mi], cfr[0]);
+    }
     __builtin_amdgcn_s_setprio(0);
 
 #define ND_SB __builtin_amdgcn_sched_barrier(0)
@@ -166,21 +183,22 @@ __global__ void __launch_bounds__(256, 2)
             int sbits = ((st < 3) ? sb : sn) | (((st + 1) & 3) << 5);
             asm volatile("" : "+s"(sbits));
             rdA(afr[nxt], sbits);
-            if (st < 3) { ldB(bfr[nxt], fq, st + 1); ldC(cfr[nxt], ch, st + 1); }
-            else { ldB(bfr[nxt], fq + c32_stride, 0); ldC(cfr[nxt], ch + 1, 0); }
+            if (st < 3) { ldC(cfr[nxt], ch, st + 1); ldB(bfr[nxt], fq, st + 1); }
+            else { ldC(cfr[nxt], ch + 1, 0); ldB(bfr[nxt], fq + c32_stride, 0); }
             // this k-step's operands: issued one k-step ago; younger = the LPS loads above (+ the 8 DMAs of k-step 3)
-            wait_vm(bfr[cur], cfr[cur], LPS + (st == 0 ? NDMA : 0));
+            wait_vm(bfr[cur][0], bfr[cur][1], LPS + (st == 0 ? NDMA : 0));
             wait_lds4(afr[cur]);
             ND_SB;
             const int dstage = ch & 1;          // behind the barrier of k-step 2 this chunk's stage is free for chunk ch + 2
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 if constexpr (GN) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = afr[cur][mi][e] * cfr[cur][0][e] + cfr[cur][1][e];
-                        if (p.gn_silu) v = fast_silu(v);
-                        afr[cur][mi][e] = v;
+                    // the NEXT k-step's fragments are normalised under this k-step's second half of MFMAs: they and their
+                    // coefficients were requested at the top; behind the coefficients only the 2 weight loads (and, in
+                    // k-step 3, the DMA rounds issued so far: 2 per mi) are younger
+                    if (mi == 2) {
+                        wait_vm(cfr[nxt][0], cfr[nxt][1], 2 + (st == 3 ? 2 * TN : 0));
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afr[nxt][0]), "+v"(afr[nxt][1]), "+v"(afr[nxt][2]), "+v"(afr[nxt][3]));
                     }
                 }
 #pragma unroll
@@ -189,6 +207,9 @@ __global__ void __launch_bounds__(256, 2)
                     for (int j = 0; j < 4; ++j) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][ni][j], afr[cur][mi][j], acc[mi][ni], 0, 0, 0);
                         if (st == 3 && j == 1) dma(mi * 2 + ni, ch + 2, dstage);          // 8 rounds over the k-step's 32 MFMAs
+                        if constexpr (GN) {
+                            if (mi >= 2 && j == 3) fold(afr[nxt][(mi - 2) * 2 + ni], cfr[nxt]);      // one fragment per 4 MFMAs
+                        }
                         ND_SB;
                     }
                 }

@@ -8,7 +8,9 @@ from nicediffusion import _hip
 shapes = [tuple(int(v) for v in s.split()) for s in sys.argv[1].split(';') if s.strip()]
 variants = [int(v) for v in sys.argv[2].split(',')]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-use_res = len(sys.argv) > 4 and sys.argv[4] == 'res'
+use_res = len(sys.argv) > 4 and 'res' in sys.argv[4]
+use_gn = len(sys.argv) > 4 and 'gn' in sys.argv[4]
+HW = 1024
 lib = _hip.load(); st = torch.cuda.current_stream().cuda_stream
 warm = False
 for (M, K, N) in shapes:
@@ -18,10 +20,11 @@ for (M, K, N) in shapes:
     w = torch.empty(lib.nd_conv_weight_floats(N, K, 1), device='cuda')
     assert lib.nd_repack_conv_weight(w0.data_ptr(), w.data_ptr(), N, K, 1, st) == 0
     fl = 2.0 * M * N * K
+    gA = torch.randn((M // HW) * K, device='cuda'); gB = torch.randn((M // HW) * K, device='cuda')
     def run(v, n):
         for _ in range(n):
             rc = lib.nd_conv_nhwc(x.data_ptr(), K, K, None, 0, 0, w.data_ptr(), b.data_ptr(), None, 0, res.data_ptr() if use_res else None, N,
-                                  out.data_ptr(), N, 1, 1, M, N, 1, 0, v, None, None, 0, st)
+                                  out.data_ptr(), N, M // HW, 32, 32, N, 1, 0, v, gA.data_ptr() if use_gn else None, gB.data_ptr() if use_gn else None, K, st)
             if rc != 0: return False
         return True
     ok = [v for v in variants if run(v, 1)]
