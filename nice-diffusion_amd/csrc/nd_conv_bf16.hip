@@ -1847,7 +1847,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     a.tiles_x = tp.tiles_x; a.tiles_y = tp.tiles_y;
     a.mt = tp.tiles_x * tp.tiles_y * tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
-    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * 2);
+    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * 2, (size_t)M * (C0 + C1) * 2);
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
     if (a.ksplit > 1) { a.silu_out = 0; a.out_f32 = 1; }

@@ -72,10 +72,20 @@ static inline int env_ngroup() {
 // n tiles per group.  Measured with FETCH_SIZE on B=64 layers (tools/ngroup_fetch.sh): all n tiles when the whole
 // weight tensor sits comfortably in an XCD's 4 MiB L2 (input then crosses HBM once: 333 MB instead of 1245 MB per
 // launch for 64x64x192->192), otherwise 4 (786 vs 1327 MB for 32x32x384->384; m-major thrashes the weights: 1883 MB).
-// Run time is within 1 % across orders -- the point is not to burn HBM bandwidth and power on re-reads.
-static inline int pick_ngroup(int nt, size_t bytes_per_ntile) {
+// Layers whose WEIGHTS outweigh their input (8x8 / 16x16 maps with 1-2 thousand input channels: 38 MB of bf16 weights
+// against 8 MB of pixels) take the n-major order instead: the m tiles of one n block run side by side on an XCD and
+// share its weight slab through L2 -- m-major made every XCD stream the whole tensor (profiles/r02_pmc_shapes.json:
+// 6.97x the algorithmic bytes on those launches), n-major re-reads only the small input once per n block.
+// Run time is within 1 % across orders where the layer is MFMA-bound -- the point there is not to burn HBM bandwidth
+// and power on re-reads; the weight-dominated layers are not MFMA-bound.
+static inline int pick_ngroup(int nt, size_t bytes_per_ntile, size_t input_bytes = 0) {
     int g = env_ngroup();
-    if (g <= 0) g = ((size_t)nt * bytes_per_ntile <= ((size_t)3 << 20)) ? nt : 4;
+    if (g <= 0) {
+        const size_t wbytes = (size_t)nt * bytes_per_ntile;
+        if (wbytes <= ((size_t)3 << 20)) g = nt;
+        else if (input_bytes > 0 && wbytes > 2 * input_bytes) g = 1;
+        else g = 4;
+    }
     return g > nt ? nt : g;
 }
 

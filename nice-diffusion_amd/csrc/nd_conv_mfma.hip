@@ -851,7 +851,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.tiles_x = best_tp.tiles_x; a.tiles_y = best_tp.tiles_y;
     a.mt = best_tp.tiles_x * best_tp.tiles_y * best_tp.groups;
     a.nt = (N + V.bn() - 1) / V.bn();
-    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float));
+    a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float), (size_t)M * (C0 + C1) * sizeof(float));
     a.vec_ok = 0; a.nhi = 0; a.zero = nullptr; a.chstats = nullptr; a.mbi = 1;
     a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;

@@ -1567,7 +1567,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     a.tiles_x = best.tiles_x; a.tiles_y = best.tiles_y;
     a.mt = best.tiles_x * best.tiles_y * best.groups;
     a.nt = (N + WN * 32 - 1) / (WN * 32);
-    a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float));
+    a.ngroup = pick_ngroup(a.nt, (size_t)WN * 32 * (C0 + C1) * 16 * sizeof(float), (size_t)NI * (H >> up) * (W >> up) * (C0 + C1) * sizeof(float));
     a.nhi = (best.hp * 8 * nsub + nt - 1) / nt;
     a.vec_ok = ((ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
                 (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
