@@ -84,7 +84,13 @@ static inline int pick_ngroup(int nt, size_t bytes_per_ntile, size_t input_bytes
         const size_t wbytes = (size_t)nt * bytes_per_ntile;
         if (wbytes <= ((size_t)3 << 20)) g = nt;
         else if (input_bytes > 0 && wbytes > 2 * input_bytes) g = 1;
-        else g = 4;
+        else {
+            // as many weight slabs as an XCD's 4 MiB L2 holds next to the streaming input, between 2 and 4 (round 3,
+            // tools/ngroup_fetch.sh on conv_wino4_kernel's 64-channel slabs: FETCH_SIZE 32x32x384->384 277 / 307 / 322 /
+            // 485 MB x2 for groups of 2 / 3 / 4 / all; 16x16x576 175 / 181 / 214 / 428; 64x64x384 1190 / 1325 / 1393 / 2030)
+            g = (int)(((size_t)4 << 20) / (bytes_per_ntile ? bytes_per_ntile : 1));
+            g = g < 2 ? 2 : (g > 4 ? 4 : g);
+        }
     }
     return g > nt ? nt : g;
 }

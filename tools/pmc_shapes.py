@@ -18,17 +18,22 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
-            'nd_conv3x3_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc')
-CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino16p_kernel', 'conv_wino_kernel', 'conv_mfma_kernel', 'gemm_stream_kernel',
-                'conv_bf16_kernel', 'conv_bf16w_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_f32_kernel')
+            'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc')
+CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino16p_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel',
+                'gemm_stream_kernel', 'conv_bf16_kernel', 'conv_bf16w_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_f32_kernel',
+                'gemm4_kernel')
+# the other kernel classes of a forward: counters aggregated per kernel name (no per-shape key)
+CLASS_KERNELS = ('attention_kernel', 'attention_bf16_kernel', 'gn_stats_kernel', 'gn_apply_kernel', 'gn_from_partials_kernel',
+                 'gn_coeffs_kernel', 'splitk_reduce_kernel')
+OUT_NAME = os.environ.get('ND_PMC_OUT', 'r03_pmc_shapes.json')
 
 
-def dispatches(d):
-    """[(dispatch id, kernel name, {counter: value}, duration_us)] of the conv kernels, in dispatch order."""
+def dispatches(d, kernels=CONV_KERNELS):
+    """[(dispatch id, kernel name, {counter: value}, duration_us)] of the named kernels, in dispatch order."""
     cc = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(cc)):
-        if not any(k in r['Kernel_Name'] for k in CONV_KERNELS) or 'pack_' in r['Kernel_Name']:
+        if not any(k in r['Kernel_Name'] for k in kernels) or 'pack_' in r['Kernel_Name']:
             continue
         e = acc.setdefault(int(r['Dispatch_Id']), [r['Kernel_Name'], collections.defaultdict(float), None])
         e[1][r['Counter_Name']] += float(r['Counter_Value'])
@@ -96,7 +101,44 @@ def main():
         if avg.get('SQ_WAVE_CYCLES'):
             rec['wait_any'] = round(avg.get('SQ_WAIT_ANY', 0.0) / avg['SQ_WAVE_CYCLES'], 4)
         out[key] = rec
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_shapes.json')
+    # ---- the non-conv classes (attention, GroupNorm): per kernel name, the dispatches of the LAST forward's share of the run
+    classes = {}
+    for d in dirs:
+        disp = dispatches(d, CLASS_KERNELS)
+        if not disp:
+            continue
+        byname = collections.defaultdict(list)
+        for (_, kname, ctr, us) in disp:
+            byname[kname.split('(')[0].replace('void ', '')].append((ctr, us))
+        for kname, lst in byname.items():
+            # keep the profiled forwards only: the last reps/(warm + reps) share is not known per kernel, so average over all
+            e = classes.setdefault(kname, dict(n=collections.defaultdict(int), sums=collections.defaultdict(float)))
+            for ctr, us in lst:
+                for c, v in ctr.items():
+                    e['sums'][c] += v
+                    e['n'][c] += 1
+                if us is not None:
+                    e['sums']['_us'] += us
+                    e['n']['_us'] += 1
+    cls_out = {}
+    nops = collections.Counter()
+    for m in ops['ops']:
+        nops[m['fn']] += 1
+    for kname, e in classes.items():
+        avg = {c: e['sums'][c] / e['n'][c] for c in e['sums']}
+        rec = dict(avg_duration_us=round(avg.get('_us', 0.0), 2), dispatches_seen=max(e['n'].values()))
+        if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
+            rec['hbm_bytes_per_launch'] = int(avg['FETCH_SIZE'] * 1024 * 2 + avg['WRITE_SIZE'] * 1024)
+            rec['fetch_kib_raw'] = round(avg['FETCH_SIZE'], 1)
+            rec['write_kib'] = round(avg['WRITE_SIZE'], 1)
+            if avg.get('_us'):
+                rec['hbm_gbps'] = round(rec['hbm_bytes_per_launch'] / avg['_us'] / 1e3, 1)
+        if avg.get('GRBM_GUI_ACTIVE', 0) > 0 and 'SQ_VALU_MFMA_BUSY_CYCLES' in avg:
+            rec['mfma_busy'] = round(avg['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (avg['GRBM_GUI_ACTIVE'] / 8), 4)
+        if avg.get('SQ_WAVE_CYCLES'):
+            rec['wait_any'] = round(avg.get('SQ_WAIT_ANY', 0.0) / avg['SQ_WAVE_CYCLES'], 4)
+        cls_out[kname] = rec
+    path = os.path.join(ROOT, 'profiles', OUT_NAME)
     merged = {}
     if os.path.exists(path):
         merged = json.load(open(path))
@@ -111,12 +153,17 @@ def main():
             by_kernel[rec['kernel']][2] += n
     merged['_totals_' + wl] = {k: dict(hbm_bytes_per_forward=int(v[0]), algorithmic_bytes_per_forward=int(v[1]),
                                        ratio=round(v[0] / v[1], 3), launches=v[2]) for k, v in by_kernel.items()}
+    merged['_classes_' + wl] = cls_out
     merged['_comment'] = ('Generated by tools/pmc_shapes.sh (rocprofv3 --pmc passes over tools/pmc_forward.py, separate passes for '
                           'FETCH_SIZE / WRITE_SIZE / SQ counters) and tools/pmc_shapes.py; key = kind:variant:k<ksize>:NI:H:W:Cin:N of a '
                           'conv launch IN the forward; hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x '
                           '1024 per launch; algorithmic_bytes = esize x (input + output elements + weights).')
-    json.dump(merged, open(path, 'w'), indent=1, sort_keys=True)
+    tmp = path + '.tmp'          # never leave a half-written table behind (bench.py reads it)
+    json.dump(merged, open(tmp, 'w'), indent=1, sort_keys=True)
+    os.replace(tmp, path)
     for k, v in merged['_totals_' + wl].items():
+        print(k, v)
+    for k, v in cls_out.items():
         print(k, v)
 
 

@@ -1,8 +1,10 @@
-# Regenerates profiles/r02_pmc_shapes.json: per-shape HBM traffic + matrix-pipe counters of every conv launch inside a
+# Regenerates profiles/r03_pmc_shapes.json (ND_PMC_OUT names another file): per-shape HBM traffic + matrix-pipe counters of every conv launch inside a
 # forward.  Run on the GPU box from the repo root:   bash tools/pmc_shapes.sh [config2|config4|config5]
 # (separate --pmc passes with --kernel-trace only, the python program directly after `--`).
 WL=${1:-config2}
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
 export ND_TUNE_CACHE=$R/gpurun_out/tune_$WL.json
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/pmc_forward.py $WL 1 > $R/gpurun_out/pmc_$WL.log 2>&1 || exit 1          # unprofiled: fills the tune cache
