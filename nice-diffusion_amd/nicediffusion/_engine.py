@@ -95,12 +95,15 @@ def _epilogue_stats_mode():
     return os.environ.get('ND_GN_EPILOGUE_STATS', 'auto')
 
 
-def _gn_partials_enabled():
-    """ND_GN_PARTIALS=0 restores one statistics pass over the (concatenated) input of every GroupNorm.  Default: every
-    tensor's per-channel sums are computed ONCE -- by the epilogue of the conv that produces it, or by one
+def _gn_partials_enabled(bf16=False):
+    """ND_GN_PARTIALS=0 restores one statistics pass over the (concatenated) input of every GroupNorm.  Default in fp32
+    plans: every tensor's per-channel sums are computed ONCE -- by the epilogue of the conv that produces it, or by one
     nd_groupnorm_channel_partials_nhwc pass over that tensor alone -- kept with the activation and re-grouped by every
-    norm that reads it, so the up path's concatenation norms (model.py:474,190) no longer re-read the skip tensors."""
-    return os.environ.get('ND_GN_PARTIALS', '1') != '0'
+    norm that reads it, so the up path's concatenation norms (model.py:474,190) no longer re-read the skip tensors
+    (statistics 2.70 -> 1.30 ms per forward at configs[1]).  bf16 plans keep the pass per norm by default: most of their
+    convs already leave epilogue statistics and the extra folds measured equal (26.2 vs 26.2 ms per step at configs[3],
+    same box, 44 more launches); ND_GN_PARTIALS=1 switches the route on there too."""
+    return os.environ.get('ND_GN_PARTIALS', '0' if bf16 else '1') != '0'
 
 
 def _bf16_epilogue_stats():
@@ -649,7 +652,7 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
-        if _gn_partials_enabled():
+        if _gn_partials_enabled(self.bf16):
             # every source that does not carry per-channel partial sums yet gets them from ONE pass over that tensor alone;
             # they stay with the activation (skip tensors are normalised again in the up path, concatenated: no re-read)
             for a in (src, src2):
