@@ -174,7 +174,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         missing = 0
         for r in g['rows']:
             NI, H, W, Cin, N = r['shape']
-            rec = tab.get('{}:{}:k{}:{}:{}:{}:{}:{}'.format(kind, var, ksize, NI, H, W, Cin, N))
+            rec = tab.get('{}{}:{}:k{}:{}:{}:{}:{}:{}'.format(kind, '+stats' if 'stats' in r['fn'] else '', var, ksize, NI, H, W, Cin, N))
             alg = esize * (NI * H * W * (Cin + N) + ksize * ksize * Cin * N)
             if rec is None:
                 missing += 1

@@ -46,6 +46,14 @@ def dispatches(d, kernels=CONV_KERNELS):
     return [(i,) + tuple(v) for i, v in sorted(acc.items())]
 
 
+def key_of(m):
+    """kind[+stats]:variant:k<ksize>:NI:H:W:Cin:N -- the statistics-writing instantiation of a kernel is a different kernel"""
+    kind, var = m['variant'] if m.get('variant') else ('direct', -1)
+    if 'stats' in m['fn']:
+        kind += '+stats'
+    return '{}:{}:k{}:{}'.format(kind, var, m.get('ksize') or 1, ':'.join(str(v) for v in (m.get('shape') or [0, 0, 0, 0, 0])))
+
+
 def main():
     wl, dirs = sys.argv[1], sys.argv[2:]
     ops = json.load(open(os.path.join(ROOT, 'gpurun_out', 'pmc_ops_{}.json'.format(wl))))
@@ -59,9 +67,7 @@ def main():
         disp = disp[-need:]
         for j, (_, kname, ctr, us) in enumerate(disp):
             m = convs[j % len(convs)]
-            kind, var = m['variant'] if m.get('variant') else ('direct', -1)
-            shape = m.get('shape') or [0, 0, 0, 0, 0]
-            key = '{}:{}:k{}:{}'.format(kind, var, m.get('ksize') or 1, ':'.join(str(v) for v in shape))
+            key = key_of(m)
             e = per_key.setdefault(key, dict(kernel=kname.split('(')[0], label=m['label'], ksize=m.get('ksize'), flops=m['flops'],
                                              n=collections.defaultdict(int), sums=collections.defaultdict(float)))
             assert e['kernel'] == kname.split('(')[0], 'dispatch order does not match the plan at {}: {} vs {}'.format(
@@ -74,9 +80,6 @@ def main():
                 e['n']['_us'] += 1
     esize = 2 if ops['dtype'] == 'bf16' else 4
 
-    def key_of(m):
-        kind, var = m['variant'] if m.get('variant') else ('direct', -1)
-        return '{}:{}:k{}:{}'.format(kind, var, m.get('ksize') or 1, ':'.join(str(v) for v in (m.get('shape') or [0, 0, 0, 0, 0])))
     counts = collections.Counter(key_of(m) for m in convs)
     out = {}
     tot_h = tot_a = 0.0
