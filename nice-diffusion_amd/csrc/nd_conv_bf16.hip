@@ -18,9 +18,21 @@
 //               global_load_dwordx4 per fragment, straight to VGPRs, three k-steps ahead (ring of 4).
 //   D^T = W.X^T a lane ends up with ONE pixel and 4 consecutive output channels per register group: 8-byte bf16 stores.
 #include "nd_conv_common.h"
+#include <type_traits>
 
 #ifndef ND_BF16_SCHED
 #define ND_BF16_SCHED 1
+#endif
+// Prologue and epilogue of a block are vector / memory instruction streams without MFMAs, while the other block of the CU
+// is in its MFMA loop at priority 1: left at priority 0 they only issue in the gaps the older block leaves (per-wave
+// timeline, tools/bf16_timeline.py: epilogue 15-19 us of a 68 us block life on 128x128 256->256).
+#ifndef ND_BF16_EDGEPRIO
+#define ND_BF16_EDGEPRIO 3
+#endif
+#if ND_BF16_EDGEPRIO
+#define ND_EDGE_PRIO() __builtin_amdgcn_s_setprio(ND_BF16_EDGEPRIO)
+#else
+#define ND_EDGE_PRIO()
 #endif
 
 namespace nd {
@@ -59,6 +71,10 @@ struct ConvArgsH {
     // by splitk_reduce_kernel, which adds the ksplit partials in order)
     int ksplit, kchunks;
     long ws_stride;
+    // conv_bf16_kernel with TN == 2: the wave's output tile goes through a wave-private LDS region (the halo buffers are
+    // dead by then) and leaves as 16-byte stores, 8 lanes = one pixel's 128 bytes = one cache line (host-checked: bf16
+    // output, N a multiple of the block's channels, 16-byte aligned rows, LDS sized for waves x TM x 4 KiB)
+    int coal;
 };
 
 // The arguments of split s, derived from the whole problem's: a convolution over the channel sub-range of that split.
@@ -100,6 +116,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     conv_bf16_kernel(const ConvArgsH pin) {
     ConvArgsH p = pin;
     if (pin.ksplit > 1) split_k_args(p, blockIdx.y, TAPS);
+#if defined(ND_BF_DIAG)
+    // diagnostic build only (tools/bf16_timeline.py): stamps go to the buffer passed as `rowbias`, which is then ignored
+    unsigned* const dg_buf = reinterpret_cast<unsigned*>(const_cast<float*>(p.rowbias));
+    p.rowbias = nullptr;
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_c1 = 0, dg_c2 = 0;
+    unsigned dg_ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ND_EDGE_PRIO();
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -147,15 +172,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // ---- halo descriptors
     const int hslot = tid % SPR;
     const int hrow0 = tid / SPR;
+    const float inv_hw = 1.0f / (float)HW, inv_hpi = 1.0f / (float)HPI;
     int gpix[MAXHI];
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) {
         const int hp = hrow0 + k * (NT / SPR);
         int g = -1;
         if (hp < HP) {
-            const int li = hp / HPI;
+            // hp < 4096, HW <= 66: (x + 0.5) * (1 / d) truncates to x / d exactly (the quotient's distance from an integer is
+            // >= 0.5 / d, the float error < 1e-3 of that) -- 18 integer divisions less in every block's prologue
+            const int li = (p.nibl == 0) ? 0 : (int)(((float)hp + 0.5f) * inv_hpi);
             const int rem = hp - li * HPI;
-            const int hy = rem / HW;
+            const int hy = (int)(((float)rem + 0.5f) * inv_hw);
             const int hx = rem - hy * HW;
             const int img = img0 + li;
             const int iy = oy0 - PAD + hy, ix = ox0 - PAD + hx;
@@ -305,12 +333,23 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         ND_PRIO(0);
     };
 
-    // ---- prologue: chunk 0 halo, first weight fragments
+    // ---- prologue: chunk 0 halo, first weight fragments.  All loads are issued before the first of them is used (one
+    //      memory latency instead of MAXHI in a row: load -> transform -> LDS store per item was 6 us of a 66 us block)
+    {
+        f32x4 ph0[MAXHI];
 #pragma unroll
-    for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0), 0);
+        for (int k = 0; k < MAXHI; ++k) ph0[k] = load_halo_pixel(gpix[k], 0);
 #pragma unroll
-    for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
+        for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, ph0[k], 0);
+    }
     __syncthreads();
+#if defined(ND_BF_DIAG)
+    dg_t1 = __builtin_amdgcn_s_memrealtime();
+    dg_c1 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
@@ -414,7 +453,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #endif
+#if defined(ND_BF_DIAG)
+        if (ch < 8) dg_ch[ch] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dg_t0);
+#endif
     }
+#if defined(ND_BF_DIAG)
+    dg_t2 = __builtin_amdgcn_s_memrealtime();
+    dg_c2 = __builtin_amdgcn_s_memtime();
+#endif
 #if defined(ND_HABL_NOEPI)
     if (p.N > 0) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.out)[0] = acc[0][0][1]; return; }
 #endif
@@ -439,12 +485,150 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             if (oy < p.H && ox < p.W && n + 7 < p.N)
                 *reinterpret_cast<f32x4*>(static_cast<__bf16*>(p.out) + (size_t)((img0 * p.H + oy) * p.W + ox) * p.ldo + n) = o.f;
         }
+#if defined(ND_BF_DIAG)
+        if (dg_buf && (tid & 63) == 0) {
+            unsigned* dg = dg_buf + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;
+            const unsigned long long dg_t3 = __builtin_amdgcn_s_memrealtime();
+            dg[0] = (unsigned)dg_t0; dg[1] = (unsigned)(dg_t1 - dg_t0); dg[2] = (unsigned)(dg_t2 - dg_t0); dg[3] = (unsigned)(dg_t3 - dg_t0);
+            dg[4] = (unsigned)(dg_c2 - dg_c1);
+            dg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            dg[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            dg[7] = (unsigned)(dg_t0 >> 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dg[8 + i] = dg_ch[i];
+        }
+#endif
         return;
     }
 #endif
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
+    ND_EDGE_PRIO();
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
+    // Two forms.  The COMMON one (whole n block inside N, vector-friendly strides, one image per block, bf16 output, no SiLU;
+    // TN == 2: LDS sized for the staging regions, p.coal) is kept small on purpose: the general form below unrolls to
+    // ~80 KB of branchy code, and a block that runs it once spends 15-19 us fetching instructions
+    // (tools/bf16_timeline.py; the I-cache is 64 KB for two CUs) -- three times what its stores cost.  Everything that
+    // can vary per launch is a compile-time copy (residual, timestep row); pixels off the image edge are handled by
+    // clamped addresses and one wave-uniform flag, not by per-store predicates.
+    constexpr bool STAGED = (TN == 2);
+    // staged stores: region of this wave = [TM*32 pixels][128 bytes], 16-byte slot s of pixel row r at slot s ^ (r & 7)
+    const bool common = vec_ok && (n0 + BN <= p.N) && p.nibl == 0 && !p.silu_out && !p.out_f32 && img0 < p.NI &&
+                        (!STAGED || p.coal != 0);
+    char* const stg = reinterpret_cast<char*>(smem) + wave * (TM * 32 * 128);
+    if (common) {
+        // per pixel row of the wave tile: validity, output row, residual row (off-image lanes point at the tile's first pixel,
+        // which is always inside: their loads are harmless and their stores are masked)
+        bool valid[TM];
+        const __bf16* rrow[TM];
+        __bf16* orow[TM];
+        bool ragged_lane = false;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = (wm * TM + mi) * 32 + l31;
+            int oy = oy0 + ((m >> p.twl) & (TH - 1));
+            int ox = ox0 + (m & (TW - 1));
+            valid[mi] = oy < p.H && ox < p.W;
+            ragged_lane |= !valid[mi];
+            oy = valid[mi] ? oy : oy0;
+            ox = valid[mi] ? ox : ox0;
+            const size_t opix = (size_t)(img0 * p.H + oy) * p.W + ox;
+            orow[mi] = static_cast<__bf16*>(p.out) + opix * p.ldo + n0 + wn * (TN * 32) + 4 * lh;
+            rrow[mi] = nullptr;
+            if (p.res) {
+                const size_t rp = p.res_up ? ((size_t)(img0 * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
+                rrow[mi] = p.res + rp * p.ldr + n0 + wn * (TN * 32) + 4 * lh;
+            }
+        }
+        const bool ragged = __builtin_amdgcn_ballot_w64(ragged_lane) != 0;      // wave-uniform
+        const float* const bptr = p.bias + n0 + wn * (TN * 32) + 4 * lh;
+        auto rows = [&](auto has_res, auto has_rb) {
+            // the additions keep the general form's order (bias, timestep row, residual): results are bit-identical to it
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                f32x4 bv[4], rbv[4], s1[4], s2[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    s1[g4] = s2[g4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bv[g4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bv[g4] = *reinterpret_cast<const f32x4*>(bptr + ni * 32 + 8 * g4);
+                    if constexpr (decltype(has_rb)::value)
+                        rbv[g4] = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img0 * p.ld_rowbias + n0 + wn * (TN * 32) + 4 * lh +
+                                                                  ni * 32 + 8 * g4);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int pxl = mi * 32 + l31;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2], acc[mi][ni][4 * g4 + 3]};
+                        v += bv[g4];                          // +0 when there is no bias
+                        if constexpr (decltype(has_rb)::value) v += rbv[g4];
+                        if constexpr (decltype(has_res)::value) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow[mi] + ni * 32 + 8 * g4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        if constexpr (STAGED) {
+                            *reinterpret_cast<bf16x4*>(stg + pxl * 128 + (((ni * 4 + g4) ^ (pxl & 7)) << 4) + lh * 8) = o;
+                        } else {
+                            if (valid[mi]) *reinterpret_cast<bf16x4*>(orow[mi] + ni * 32 + 8 * g4) = o;
+                        }
+                        if constexpr (STATS) {      // sums of what was stored: the statistics are those of the bf16 tensor
+                            f32x4 of = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+                            if (ragged) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) of[e] = valid[mi] ? of[e] : 0.f;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                s1[g4][e] += of[e];
+                                s2[g4][e] += of[e] * of[e];
+                            }
+                        }
+                    }
+                }
+                if constexpr (STATS) {
+                    // per-channel sums over this wave's TM x 32 pixels -> row (pixel tile, wave row) of p.chstats (same order of
+                    // additions as the general form: mi ascending, then the 32-lane reduction)
+                    float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N +
+                                n0 + (wn * TN + ni) * 32 + 4 * lh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        sum8_over_32_lanes(s1[g4], s2[g4]);
+                        if (l31 == 31) {
+                            *reinterpret_cast<f32x4*>(cs + 8 * g4) = s1[g4];
+                            *reinterpret_cast<f32x4*>(cs + p.N + 8 * g4) = s2[g4];
+                        }
+                    }
+                }
+#if defined(ND_BF_DIAG)
+                if (ni == 0) dg_ch[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dg_t0);
+#endif
+            }
+        };
+        if (p.res) {
+            if (p.rowbias) rows(std::true_type{}, std::true_type{});
+            else rows(std::true_type{}, std::false_type{});
+        } else {
+            if (p.rowbias) rows(std::false_type{}, std::true_type{});
+            else rows(std::false_type{}, std::false_type{});
+        }
+        if constexpr (STAGED) {
+            // the wave reads its region back row-major: 8 lanes = the 8 slots of one pixel row = 128 contiguous bytes of the output
+            __bf16* const obase = static_cast<__bf16*>(p.out) + n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int it = 0; it < TM * 4; ++it) {
+                const int pxl = it * 8 + (lane >> 3);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + pxl * 128 + (((lane & 7) ^ (pxl & 7)) << 4));
+                const int m = wm * TM * 32 + pxl;
+                const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+                const int ox = ox0 + (m & (TW - 1));
+                if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v;
+            }
+        }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = (wm * TM + mi) * 32 + l31;
@@ -511,8 +695,19 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
+#if defined(ND_BF_DIAG)
+        if (mi == 0) dg_ch[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dg_t0);
+#endif
     }
-    if constexpr (STATS) {
+    }
+#if defined(ND_BF_DIAG)
+    dg_ch[6] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dg_t0);
+#if defined(ND_BF_DIAG_DRAIN)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dg_ch[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dg_t0);
+#endif
+#endif
+    if (STATS && !common) {
         // per-channel sums / sums of squares of the stored values over this wave's TM x 32 pixels -> row (pixel tile, wave
         // row) of p.chstats.  Host-checked: one image per block, N % 4 == 0, vector-friendly strides, bf16 output.
         float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N;
@@ -539,6 +734,19 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             }
         }
     }
+#if defined(ND_BF_DIAG)
+    if (dg_buf && (tid & 63) == 0) {
+        unsigned* dg = dg_buf + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;
+        const unsigned long long dg_t3 = __builtin_amdgcn_s_memrealtime();
+        dg[0] = (unsigned)dg_t0; dg[1] = (unsigned)(dg_t1 - dg_t0); dg[2] = (unsigned)(dg_t2 - dg_t0); dg[3] = (unsigned)(dg_t3 - dg_t0);
+        dg[4] = (unsigned)(dg_c2 - dg_c1);
+        dg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+        dg[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+        dg[7] = (unsigned)(dg_t0 >> 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dg[8 + i] = dg_ch[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1507,6 +1715,11 @@ static const VariantH kVariantsH[] = {
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
+static bool coal_epilogue_enabled() {
+    static const int v = [] { const char* e = getenv("ND_BF16_COAL_EPI"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
 static size_t lds_bytes_h(int taps, int hp) { return (size_t)2 * hp * (taps == 9 ? 128 : 256); }
 static size_t lds_bytes_w(const VariantH& V, int hp) {
     return (size_t)2 * ((hp * 8 + 63) / 64) * 1024 + (size_t)2 * 4 * (V.bn() / 32) * 1024 + (size_t)V.nt() / 64 * 1024;
@@ -1893,7 +2106,20 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
         return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
 #endif
     }
-    const size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
+    size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
+    a.coal = 0;
+    if (coal_epilogue_enabled() && !V.mf && V.tn == 2 && !a.out_f32 && a.ksplit <= 1 && N % V.bn() == 0 && (ldo & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        // the staging region must not cost a resident block: two 4-wave blocks per CU stay two
+        const size_t stage = (size_t)(V.nt() / 64) * V.tm * 32 * 128;
+        const size_t lds2 = lds > stage ? lds : stage;
+        const size_t cap = 160 * 1024;
+        const size_t want = (V.nt() == 256 && cap / lds >= 2) ? 2 : 1;
+        if (lds2 <= cap && cap / lds2 >= want) {
+            a.coal = 1;
+            lds = lds2;
+        }
+    }
     if (chstats) return dispatch_h_stats(v, a, grid, lds, s);
     const int rc = (taps == 9) ? dispatch_h<9>(v, a, grid, lds, s) : dispatch_h<1>(v, a, grid, lds, s);
     if (rc != ND_OK || a.ksplit <= 1) return rc;
