@@ -17,7 +17,7 @@
 //   B operand   weights, pre-packed into fragment order [c64][n tile][tap][k-step][lane][8 bf16]: one coalesced 1 KiB
 //               global_load_dwordx4 per fragment, straight to VGPRs, three k-steps ahead (ring of 4).
 //   D^T = W.X^T a lane ends up with ONE pixel and 4 consecutive output channels per register group: 8-byte bf16 stores.
-#include "nd_conv_common.h"
+#include "nd_conv_bf16_args.h"
 #include <type_traits>
 
 #ifndef ND_BF16_SCHED
@@ -36,46 +36,6 @@
 #endif
 
 namespace nd {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgsH {
-    const __bf16* x0;
-    const __bf16* x1;
-    const __bf16* w;      // packed fragments
-    const float* bias;
-    const float* rowbias;
-    const __bf16* res;
-    void* out;            // bf16, or fp32 when out_f32
-    int C0, C1, ldx0, ldx1;
-    int NI, H, W;         // output (= virtual input) size
-    int Hs, Ws;           // stored input size (H >> up)
-    int up, res_up;
-    int N, ldo, ldr, ld_rowbias;
-    int NT32, NC64;
-    int thl, twl, nibl;
-    int tiles_x, tiles_y, mt, nt, ngroup;
-    int silu_out, out_f32;
-    // GroupNorm apply fused into the loader: in' = act(in * gnA[img][c] + gnB[img][c]) for real (non-padding) pixels;
-    // one image per block (gn_hw > 0: flat pixel list, image = pixel / gn_hw)
-    const float* gnA;
-    const float* gnB;
-    int ld_gn, gn_silu, gn_hw;
-    // partial GroupNorm statistics of the OUTPUT (STATS instantiations): rows [img][cs_rows][sum | sum of squares][N],
-    // one row per (pixel tile of the image, wave row), every row written by every launch
-    float* chstats;
-    int cs_rows;
-    // split over K (gridDim.y = ksplit > 1): block row s computes channels [s * kchunks * 64, ...) only and writes its raw
-    // fp32 accumulators to out + s * ws_stride floats (out is then the workspace; bias / residual / activation are applied
-    // by splitk_reduce_kernel, which adds the ksplit partials in order)
-    int ksplit, kchunks;
-    long ws_stride;
-    // conv_bf16_kernel with TN == 2: the wave's output tile goes through a wave-private LDS region (the halo buffers are
-    // dead by then) and leaves as 16-byte stores, 8 lanes = one pixel's 128 bytes = one cache line (host-checked: bf16
-    // output, N a multiple of the block's channels, 16-byte aligned rows, LDS sized for waves x TM x 4 KiB)
-    int coal;
-};
 
 // The arguments of split s, derived from the whole problem's: a convolution over the channel sub-range of that split.
 __device__ __forceinline__ void split_k_args(ConvArgsH& p, int s, int taps) {
@@ -105,11 +65,6 @@ __device__ __forceinline__ void split_k_args(ConvArgsH& p, int s, int taps) {
     p.out = static_cast<float*>(p.out) + (size_t)s * p.ws_stride;
 }
 
-__device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
-    union { f32x4 f; bf16x8 h; } u;
-    u.f = v;
-    return u.h;
-}
 
 template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
@@ -220,14 +175,16 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     unsigned vmask = 0;
 #pragma unroll
     for (int k = 0; k < MAXHI; ++k) vmask |= (gpix[k] >= 0 ? 1u : 0u) << k;
-    if (gn) {
-        const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
-        for (int c = tid; c < CPAD; c += NT) {
-            cfA[c] = (c < Ctot) ? p.gnA[(size_t)gimg * p.ld_gn + c] : 0.f;
-            cfB[c] = (c < Ctot) ? p.gnB[(size_t)gimg * p.ld_gn + c] : 0.f;
+    auto stage_gn_coeffs = [&]() {
+        if (gn) {
+            const int gimg = (p.gn_hw > 0) ? (ox0 / p.gn_hw) : img0;
+            for (int c = tid; c < CPAD; c += NT) {
+                cfA[c] = (c < Ctot) ? p.gnA[(size_t)gimg * p.ld_gn + c] : 0.f;
+                cfB[c] = (c < Ctot) ? p.gnB[(size_t)gimg * p.ld_gn + c] : 0.f;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
     auto gn_xform = [&](f32x4 raw, int ch, bool valid) -> f32x4 {
         if (!gn || !valid) return raw;
         const int c = ch * (64 * NSUB) + (hslot << 3);
@@ -342,6 +299,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
         for (int d = 0; d < BDIST; ++d) advance_b(b_fr[d]);
         __builtin_amdgcn_sched_barrier(0);
+        stage_gn_coeffs();      // behind the loads: the coefficient table's own latency hides under theirs
 #pragma unroll
         for (int k = 0; k < MAXHI; ++k) store_halo_item(k, 0, ph0[k], 0);
     }
@@ -509,29 +467,22 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // TN == 2: LDS sized for the staging regions, p.coal) is kept small on purpose: the general form below unrolls to
     // ~80 KB of branchy code, and a block that runs it once spends 15-19 us fetching instructions
     // (tools/bf16_timeline.py; the I-cache is 64 KB for two CUs) -- three times what its stores cost.  Everything that
-    // can vary per launch is a compile-time copy (residual, timestep row); pixels off the image edge are handled by
-    // clamped addresses and one wave-uniform flag, not by per-store predicates.
+    // can vary per launch is a compile-time copy (residual, timestep row); tiles that reach over the image edge take the
+    // general form.
     constexpr bool STAGED = (TN == 2);
     // staged stores: region of this wave = [TM*32 pixels][128 bytes], 16-byte slot s of pixel row r at slot s ^ (r & 7)
     const bool common = vec_ok && (n0 + BN <= p.N) && p.nibl == 0 && !p.silu_out && !p.out_f32 && img0 < p.NI &&
-                        (!STAGED || p.coal != 0);
+                        oy0 + TH <= p.H && ox0 + TW <= p.W && (!STAGED || p.coal != 0);
     char* const stg = reinterpret_cast<char*>(smem) + wave * (TM * 32 * 128);
     if (common) {
-        // per pixel row of the wave tile: validity, output row, residual row (off-image lanes point at the tile's first pixel,
-        // which is always inside: their loads are harmless and their stores are masked)
-        bool valid[TM];
+        // per pixel row of the wave tile: output row, residual row (the whole tile lies inside the image: no masks)
         const __bf16* rrow[TM];
         __bf16* orow[TM];
-        bool ragged_lane = false;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const int m = (wm * TM + mi) * 32 + l31;
-            int oy = oy0 + ((m >> p.twl) & (TH - 1));
-            int ox = ox0 + (m & (TW - 1));
-            valid[mi] = oy < p.H && ox < p.W;
-            ragged_lane |= !valid[mi];
-            oy = valid[mi] ? oy : oy0;
-            ox = valid[mi] ? ox : ox0;
+            const int oy = oy0 + ((m >> p.twl) & (TH - 1));
+            const int ox = ox0 + (m & (TW - 1));
             const size_t opix = (size_t)(img0 * p.H + oy) * p.W + ox;
             orow[mi] = static_cast<__bf16*>(p.out) + opix * p.ldo + n0 + wn * (TN * 32) + 4 * lh;
             rrow[mi] = nullptr;
@@ -540,7 +491,6 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 rrow[mi] = p.res + rp * p.ldr + n0 + wn * (TN * 32) + 4 * lh;
             }
         }
-        const bool ragged = __builtin_amdgcn_ballot_w64(ragged_lane) != 0;      // wave-uniform
         const float* const bptr = p.bias + n0 + wn * (TN * 32) + 4 * lh;
         auto rows = [&](auto has_res, auto has_rb) {
             // the additions keep the general form's order (bias, timestep row, residual): results are bit-identical to it
@@ -573,14 +523,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         if constexpr (STAGED) {
                             *reinterpret_cast<bf16x4*>(stg + pxl * 128 + (((ni * 4 + g4) ^ (pxl & 7)) << 4) + lh * 8) = o;
                         } else {
-                            if (valid[mi]) *reinterpret_cast<bf16x4*>(orow[mi] + ni * 32 + 8 * g4) = o;
+                            *reinterpret_cast<bf16x4*>(orow[mi] + ni * 32 + 8 * g4) = o;
                         }
                         if constexpr (STATS) {      // sums of what was stored: the statistics are those of the bf16 tensor
-                            f32x4 of = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
-                            if (ragged) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) of[e] = valid[mi] ? of[e] : 0.f;
-                            }
+                            const f32x4 of = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 s1[g4][e] += of[e];
@@ -625,7 +571,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 const int m = wm * TM * 32 + pxl;
                 const int oy = oy0 + ((m >> p.twl) & (TH - 1));
                 const int ox = ox0 + (m & (TW - 1));
-                if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v;
+                *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v;
             }
         }
     } else {
@@ -1712,6 +1658,9 @@ static const VariantH kVariantsH[] = {
     {2, 2, 4, 2, 0, 1},   // 19: 128 x  64, 4 waves
     // GEMM-shaped 1x1 (flat pixel lists only): three LDS stages filled by LDS-DMA; coded as ldsw = 2
     {4, 2, 2, 2, 2, 0},   // 20: 256 x 128, 8 waves
+    // GEMM-shaped 1x1, two blocks per CU (nd_gemm_bf16_quad.hip): pixel rows through 4 LDS stages by LDS-DMA, weights
+    // global -> VGPR; coded as ldsw = 3
+    {1, 4, 4, 2, 3, 0},   // 21: 128 x 256, 4 waves
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
@@ -1742,8 +1691,8 @@ static bool plan_tiles_h(const VariantH& V, int taps, int NI, int H, int W, Tile
             const int nibl = lbm - twl - thl;
             const int TW = 1 << twl, TH = 1 << thl, NIB = 1 << nibl;
             const int hp = NIB * (TH + 2 * pad) * (TW + 2 * pad);
-            if (V.ldsw == 2) {
-                if (thl != 0 || nibl != 0) continue;                       // a flat run of 256 pixels
+            if (V.ldsw >= 2) {
+                if (thl != 0 || nibl != 0) continue;                       // a flat run of 256 (128) pixels
             } else if (V.ldsw) {
                 if ((hp * 8 + 63) / 64 > 9 * (nt / 64)) continue;        // one 1 KiB halo piece per wave and tap
                 if (lds_bytes_w(V, hp) > 160 * 1024) continue;
@@ -1777,14 +1726,14 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
         if (V.ldsw == 1 && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
-        if (V.ldsw == 2 && (taps != 1 || variant < 0 || pNI != 1 || pH != 1)) continue;      // flat 1x1 only, explicit choice only
+        if (V.ldsw >= 2 && (taps != 1 || variant < 0 || pNI != 1 || pH != 1)) continue;      // flat 1x1 only, explicit choice only
         if (V.mf && variant < 0) continue;                        // needs the layout-1 weights: explicit choice only
         if (V.mf && V.tm * V.tn >= 32) continue;                  // 128 px x 64 ch wave tile on 16x16 MFMAs: 154 registers spill (10x slower); kept only as an index
         TilePlan tp;
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
         const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = V.ldsw == 2 ? (size_t)3 * 48 * 1024 : (V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp));
+        const size_t lds = V.ldsw == 3 ? (size_t)64 * 1024 : V.ldsw == 2 ? (size_t)3 * 48 * 1024 : (V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp));
         int per_cu = (int)(160 * 1024 / lds);
         const int by_waves = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;      // two waves per SIMD
         if (per_cu > by_waves) per_cu = by_waves;
@@ -1917,7 +1866,8 @@ extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int k
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
         int p;
-        if (V.ldsw == 2) p = 0;                                                                   // gemm_bf16_kernel: real chunks only
+        if (V.ldsw == 3) p = wstream::pad_chunks(wstream::kBf16GemmQAheadSteps, wstream::bf16_steps(1));      // gemm_bf16q_kernel: one chunk
+        else if (V.ldsw == 2) p = 0;                                                              // gemm_bf16_kernel: real chunks only
         else if (V.ldsw == 1) p = wstream::pad_chunks(wstream::kBf16DmaAheadTaps, taps);           // conv_bf16w_kernel
         else if (V.mf) p = wstream::pad_chunks(wstream::bf16s_ring(V.tn, taps) - 1, wstream::bf16s_steps(taps));
         else p = wstream::pad_chunks(wstream::bf16_ring(taps) - 1, wstream::bf16_steps(taps));
@@ -1939,7 +1889,7 @@ extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int k
 extern "C" const char* nd_conv_bf16_variant_name(int variant) {
     if (variant < 0 || variant >= kNumVariantsH) return "";
     const VariantH& v = kVariantsH[variant];
-    return v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
+    return v.ldsw == 3 ? "nd::gemm_bf16q_kernel" : v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
                                                                                                : "nd::conv_bf16_kernel";
 }
 
@@ -2082,6 +2032,17 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     }
     const int grid = a.mt * a.nt;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (V.ldsw == 3) {
+        ND_REQUIRE(gnA == nullptr && rowbias == nullptr && !a.out_f32 && !a.silu_out && a.ksplit <= 1 && !a.up && !a.res_up, fn,
+                   "the two-block GEMM form takes plain 1x1 convolutions with bf16 output only");
+        ND_REQUIRE(M % 128 == 0 && N % 256 == 0 && C0 % 64 == 0 && C1 % 64 == 0, fn,
+                   "the two-block GEMM form needs M % 128 == 0, N % 256 == 0 and whole 64-channel chunks");
+        ND_REQUIRE((ldo & 7) == 0 && (!residual || (ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0, fn,
+                   "the two-block GEMM form needs 16-byte aligned output rows");
+        ND_REQUIRE((double)M * ldx0 * 2 < 2147483648.0 && (double)M * (C1 ? ldx1 : 0) * 2 < 2147483648.0, fn,
+                   "the two-block GEMM form addresses its inputs with 32-bit buffer offsets (< 2 GiB)");
+        return launch_gemm_bf16q(a, grid, s);
+    }
     if (V.ldsw == 2) {
         ND_REQUIRE(gnA == nullptr && rowbias == nullptr, fn, "the GEMM form takes plain 1x1 convolutions only");
         const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;

@@ -38,6 +38,7 @@ constexpr int bf16_ring(int taps) { return taps == 9 ? 3 : 4; }                 
 constexpr int bf16s_ring(int tn, int taps) { return tn >= 4 ? 2 : (taps == 9 ? 3 : 4); }          // conv_bf16s_kernel
 constexpr int bf16_steps(int taps) { return taps * 4; }
 constexpr int bf16s_steps(int taps) { return taps * 2; }
+constexpr int kBf16GemmQAheadSteps = 4; // gemm_bf16q_kernel: the next chunk's four k-steps
 constexpr int kBf16DmaAheadTaps = 1;      // conv_bf16w_kernel: the next tap's stage (a chunk has `taps` of them)
 
 }  // namespace wstream

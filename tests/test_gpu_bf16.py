@@ -134,7 +134,8 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
                                          out.data_ptr(), Cout, B, H, W, Cout, ksize, _hip.CONV_OUT_F32 if f32out else 0,
                                          v, None, None, 0, st())
             if rc != 0:
-                assert v >= 0 and ('no tile variant fits' in _hip.last_error() or 'not built' in _hip.last_error()), (v, _hip.last_error())
+                assert v >= 0 and any(m in _hip.last_error() for m in ('no tile variant fits', 'not built', 'two-block GEMM form')), \
+                    (v, _hip.last_error())
                 continue
             ran += 1
             got = from_nhwc(out, B, H, W, Cout)
@@ -144,6 +145,52 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
             else:
                 assert (err <= _tol_bf16(ref)).all(), (v, err.max().item())
     assert ran >= 4
+
+
+GEMMQ = 21      # gemm_bf16q_kernel: 128 px x 256 ch, two blocks per CU (nd_gemm_bf16_quad.hip)
+
+
+@pytest.mark.parametrize('B,C0,C1,N,H,W,res,pad', [
+    (2, 128, 0, 256, 16, 16, False, 0), (1, 64, 64, 512, 16, 8, True, 0), (3, 192, 64, 256, 8, 16, True, 16),
+    (2, 64, 0, 256, 8, 8, False, 8), (1, 512, 0, 768, 32, 32, True, 0)])
+def test_gemm_bf16_two_blocks_per_cu(B, C0, C1, N, H, W, res, pad):
+    """Variant 21 of nd_conv_bf16_nhwc (1x1 on a flat pixel list, rows by LDS-DMA, weights global -> VGPR, staged 16-byte
+    stores) against float64 on the bf16-rounded operands, and bit for bit against the 3-stage GEMM form (variant 20: same
+    order of accumulation); two-source input, residual, strided output rows; what it does not take is refused by name."""
+    assert lib().nd_conv_bf16_variant_name(GEMMQ) == b'nd::gemm_bf16q_kernel'
+    xa = rnd(B, C0, H, W, seed=1)
+    xb = rnd(B, C1, H, W, seed=2) if C1 else None
+    w = rnd(N, C0 + C1, seed=3, scale=0.05)
+    b = rnd(N, seed=4)
+    r = rnd(B, N, H, W, seed=5) if res else None
+    xin = q(xa) if xb is None else torch.cat([q(xa), q(xb)], 1)
+    ref = F.conv2d(xin.double(), q(w).double()[:, :, None, None], b.double())
+    if res:
+        ref = ref + q(r).double()
+    ref = ref.float()
+    xad, xbd = nhwc_bf(xa, C0 + pad), (nhwc_bf(xb, C1 + pad) if C1 else None)
+    wd, bd, rd = pack_bf(w), b.to(DEV), (nhwc_bf(r) if res else None)
+    ldo = N + pad
+    outs = {}
+    for v in (GEMMQ, 20):
+        out = torch.zeros(B * H * W * ldo, dtype=BF, device=DEV)
+        _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(),
+                                           None, 0, _hip.ptr(rd), N if res else 0, out.data_ptr(), ldo, B, H, W, N, 1, 0, v, None, None, 0, st()),
+                   'variant %d' % v)
+        outs[v] = out
+        err = (from_nhwc(out, B, H, W, N, ldo) - ref).abs()
+        assert (err <= _tol_bf16(ref)).all(), (v, err.max().item())
+        if pad:
+            assert not out.view(B, H, W, ldo)[..., N:].any()
+    assert torch.equal(outs[GEMMQ], outs[20])
+    # refused, with the reason: fp32 output, SiLU, N not a multiple of 256, M not a multiple of 128, a per-image bias row
+    out32 = torch.zeros(B * H * W * ldo, dtype=torch.float32, device=DEV)
+    rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                 None, 0, out32.data_ptr(), ldo, B, H, W, N, 1, _hip.CONV_OUT_F32, GEMMQ, None, None, 0, st())
+    assert rc != 0 and 'two-block GEMM form' in _hip.last_error()
+    rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                 None, 0, outs[20].data_ptr(), ldo, B, H, W, N - 32, 1, 0, GEMMQ, None, None, 0, st())
+    assert rc != 0 and 'two-block GEMM form' in _hip.last_error()
 
 
 def test_conv_bf16_fused_options():
