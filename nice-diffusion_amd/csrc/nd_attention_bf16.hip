@@ -52,9 +52,15 @@ __global__ void __launch_bounds__(256)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y;
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin by their linear id, so the q tiles of one (image, head) --
+    // which stream the same K / V -- would land on 8 different L2s (PMC: 6x the algorithmic bytes fetched); give every XCD
+    // a contiguous run of (bh, q tile) pairs instead (the map of the convolution kernels, nd_conv_mfma.hip)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+    const int xq = total >> 3, xr = total & 7, xcd = lin & 7;
+    const int idp = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int bh = idp / (int)gridDim.x, qtile = idp - bh * (int)gridDim.x;
     const int b = bh / p.heads, head = bh - b * p.heads;
-    const int q0 = blockIdx.x * BQ + wave * 32;
+    const int q0 = qtile * BQ + wave * 32;
     const size_t rowbase = (size_t)b * p.T;
     const int hoff = head * p.head_stride;
 
