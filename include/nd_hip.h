@@ -146,6 +146,9 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
  *   ND_CONV_OUT_F32 `out` is float* and receives the fp32 accumulators (the UNet's last conv, feeding the fp32 sampler
  *   update).  `w` comes from nd_repack_conv_weight_bf16 (fp32 OIHW -> bf16 fragment order
  *   [c64][n tile][tap][k-step][lane][8], nd_conv_bf16_weight_elems elements).  `variant` < 0: cost model.
+ *   Variants are tile shapes of three kernel families (nd_conv_bf16_variant_name); 20 and 21 are the GEMM-shaped 1x1
+ *   forms on flat pixel lists (21: 128 px x 256 ch, two blocks per CU -- M % 128 == 0, N % 256 == 0, whole 64-channel
+ *   chunks, plain bf16 output); a variant that cannot take a launch returns ND_E_ARG with the reason.
  *   gnA/gnB [NI][ld_gn] fp32 | NULL: GroupNorm(+AdaGN)(+SiLU with ND_CONV_GN_SILU) of the INPUT applied by the loader
  *   (coefficients from nd_groupnorm_coeffs; padding stays zero); needs one image per block (H*W >= the pixel tile).
  * nd_f32_to_bf16_rows: [rows][ldx] fp32 -> [rows][ldo] bf16, channels [C, ldo) zeroed (x_t enters the bf16 UNet).
