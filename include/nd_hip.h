@@ -243,6 +243,12 @@ int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const f
 int nd_groupnorm_coeffs(const double* partials, int nblocks, const float* gamma, const float* beta, const float* scale,
                         const float* shift, int ld_ss, float* coefA, float* coefB, int ld_coef,
                         int NI, int C, int HW, int G, float eps, nd_stream_t stream);
+/* nd_groupnorm_stats_from_partials + nd_groupnorm_coeffs in one launch (same order of additions, same arithmetic: the
+ * coefficients are bit-identical to the two-step form), for norms whose only consumer is a convolution's loader. */
+int nd_groupnorm_coeffs_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
+                                      const float* gamma, const float* beta, const float* scale, const float* shift,
+                                      int ld_ss, float* coefA, float* coefB, int ld_coef, int NI, int HW, int G,
+                                      float eps, nd_stream_t stream);
 int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, const double* partials, int nblocks,
                             const float* gamma, const float* beta,

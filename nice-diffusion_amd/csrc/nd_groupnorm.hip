@@ -403,6 +403,65 @@ __global__ void __launch_bounds__(128)
     }
 }
 
+// The two kernels above in one launch, for norms that are applied by a convolution's loader (nd_groupnorm_coeffs right
+// behind nd_groupnorm_stats_from_partials: 38 pairs of 5-6 us launches per forward of BASELINE configs[3]): the block of
+// (group, image) folds the partial rows exactly as gn_from_partials_kernel does -- same items per thread, same tree, so
+// the float64 sums are the same bits -- and its first C / G threads write the group's channels' coefficients with
+// gn_coeffs_kernel's arithmetic.
+__global__ void __launch_bounds__(128)
+    gn_coeffs_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, const float* gamma,
+                                   const float* beta, const float* scale, const float* shift, int ld_ss, float* coefA,
+                                   float* coefB, int ld_coef, int HW, int G, float eps) {
+    __shared__ double red[2][128];
+    const int g = blockIdx.x, img = blockIdx.y;
+    const int C = C0 + C1;
+    const int cpg = C / G;
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int n0 = c_lo < C0 ? ((c_hi < C0 ? c_hi : C0) - c_lo) : 0;
+    const int n1 = cpg - n0;
+    for (int i = t; i < rows0 * n0; i += 128) {
+        const int r = i / n0, cc = c_lo + (i - r * n0);
+        const float* q = p0 + (((size_t)img * rows0 + r) * 2) * C0 + cc;
+        a += (double)q[0];
+        b += (double)q[C0];
+    }
+    const int c1_lo = (c_lo > C0 ? c_lo : C0) - C0;
+    for (int i = t; i < rows1 * n1; i += 128) {
+        const int r = i / n1, cc = c1_lo + (i - r * n1);
+        const float* q = p1 + (((size_t)img * rows1 + r) * 2) * C1 + cc;
+        a += (double)q[0];
+        b += (double)q[C1];
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    for (int w = 64; w > 0; w >>= 1) {
+        if (t < w) {
+            red[0][t] += red[0][t + w];
+            red[1][t] += red[1][t + w];
+        }
+        __syncthreads();
+    }
+    const double inv_n = 1.0 / ((double)cpg * (double)HW);
+    const double mean = red[0][0] * inv_n;
+    double var = red[1][0] * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int c = c_lo + t; c < c_hi; c += 128) {
+        double ca = rstd * (double)gamma[c];
+        double cb = (double)beta[c] - mean * ca;
+        if (scale) {
+            const double sc = 1.0 + (double)scale[(size_t)img * ld_ss + c];
+            ca *= sc;
+            cb = cb * sc + (double)shift[(size_t)img * ld_ss + c];
+        }
+        coefA[(size_t)img * ld_coef + c] = (float)ca;
+        coefB[(size_t)img * ld_coef + c] = (float)cb;
+    }
+}
+
 // pixel chunks per image of the statistics pass: enough blocks to fill the chip (~2048), at least 4 pixels per
 // pixel-row of threads
 static void stats_geometry(int NI, int HW, int CQ, int* QX, int* PY, int* ppb, int* chunks) {
@@ -561,3 +620,19 @@ extern "C" int nd_groupnorm_stats_from_partials(const float* p0, int C0, int row
                        rows0, C1 > 0 ? p1 : p0, C1, C1 > 0 ? rows1 : 0, stats, G);
     return check_launch(fn);
 }
+
+extern "C" int nd_groupnorm_coeffs_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
+                                                const float* gamma, const float* beta, const float* scale, const float* shift,
+                                                int ld_ss, float* coefA, float* coefB, int ld_coef, int NI, int HW, int G,
+                                                float eps, nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_coeffs_from_partials";
+    ND_REQUIRE(p0 && gamma && beta && coefA && coefB && NI > 0 && HW > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 128 &&
+               (C0 + C1) % G == 0, fn, "bad arguments");
+    if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
+    ND_REQUIRE((scale == nullptr) == (shift == nullptr) && ld_coef >= C0 + C1, fn, "scale/shift go together; ld_coef >= C");
+    hipLaunchKernelGGL(gn_coeffs_from_partials_kernel, dim3(G, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
+                       rows0, C1 > 0 ? p1 : p0, C1, C1 > 0 ? rows1 : 0, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef,
+                       HW, G, eps);
+    return check_launch(fn);
+}
+

@@ -78,9 +78,10 @@ class Act:
 class Normed:
     """GroupNorm output that has not been materialised: the consumer conv applies ``x * A + B`` (+SiLU) while loading.
     The conv emits nd_groupnorm_coeffs (fp32 [NI][C] A/B) first, or falls back to the explicit apply kernel."""
-    __slots__ = ('src', 'src2', 'C', 'silu', 'norm', 'scale_ptr', 'shift_ptr', 'ld_ss', 'slot', 'nblk')
+    __slots__ = ('src', 'src2', 'C', 'silu', 'norm', 'scale_ptr', 'shift_ptr', 'ld_ss', 'slot', 'nblk', 'pending')
 
     def __init__(self, **kw):
+        self.pending = None       # (args, label) of a nd_groupnorm_stats_from_partials launch not emitted yet
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -104,6 +105,12 @@ def _gn_partials_enabled(bf16=False):
     convs already leave epilogue statistics and the extra folds measured equal (26.2 vs 26.2 ms per step at configs[3],
     same box, 44 more launches); ND_GN_PARTIALS=1 switches the route on there too."""
     return os.environ.get('ND_GN_PARTIALS', '0' if bf16 else '1') != '0'
+
+
+def _gn_merge_coeffs():
+    """ND_GN_MERGE_COEFFS (default 1): a norm whose statistics come from partial rows and whose consumer applies it in its
+    loader gets ONE launch (nd_groupnorm_coeffs_from_partials) instead of the fold + the coefficient kernel."""
+    return os.environ.get('ND_GN_MERGE_COEFFS', '1') != '0'
 
 
 def _bf16_epilogue_stats():
@@ -283,10 +290,7 @@ class UNetPlan:
                 coefA = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 coefB = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 self.keep += [coefA, coefB]
-                self._emit(self.lib.nd_groupnorm_coeffs,
-                           [('gnstats', nm.slot), nm.nblk, nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(),
-                            nm.scale_ptr, nm.shift_ptr, nm.ld_ss, coefA.data_ptr(), coefB.data_ptr(), nm.C, nm.src.NI,
-                            nm.C, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS], 'gn.coeffs')
+                self._emit_coeffs(nm, coefA, coefB)
                 gn = [coefA.data_ptr(), coefB.data_ptr(), nm.C]
                 if nm.silu:
                     flags |= _hip.CONV_GN_SILU
@@ -333,8 +337,29 @@ class UNetPlan:
             self._release(tmp)
         return out
 
+    def _stats_ready(self, nm):
+        """Emit the deferred fold of the partial rows (the consumer reads the float64 group statistics)."""
+        if nm.pending is not None:
+            self._emit(self.lib.nd_groupnorm_stats_from_partials, *nm.pending)
+            nm.pending = None
+
+    def _emit_coeffs(self, nm, coefA, coefB):
+        """Per-(image, channel) coefficients of a norm applied by a convolution's loader."""
+        tail = [nm.norm.weight.detach().data_ptr(), nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr, nm.ld_ss,
+                coefA.data_ptr(), coefB.data_ptr(), nm.C]
+        if nm.pending is not None:
+            pa = nm.pending[0]
+            self._emit(self.lib.nd_groupnorm_coeffs_from_partials,
+                       pa[:6] + tail + [nm.src.NI, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS], 'gn.coeffs')
+            nm.pending = None
+        else:
+            self._emit(self.lib.nd_groupnorm_coeffs,
+                       [('gnstats', nm.slot), nm.nblk] + tail + [nm.src.NI, nm.C, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS],
+                       'gn.coeffs')
+
     def _materialise(self, nm):
         """Fallback for consumers that cannot fuse the GroupNorm affine: write the normalised tensor."""
+        self._stats_ready(nm)
         s2 = (None, 0, 0) if nm.src2 is None else (nm.src2.ptr, nm.src2.C, nm.src2.ld)
         out = self._new(nm.src.NI, nm.src.H, nm.src.W, nm.C)
         args = [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', nm.slot), nm.nblk,
@@ -383,10 +408,7 @@ class UNetPlan:
                 coefA = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 coefB = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 self.keep += [coefA, coefB]
-                self._emit(self.lib.nd_groupnorm_coeffs,
-                           [('gnstats', nm.slot), nm.nblk, nm.norm.weight.detach().data_ptr(),
-                            nm.norm.bias.detach().data_ptr(), nm.scale_ptr, nm.shift_ptr, nm.ld_ss, coefA.data_ptr(),
-                            coefB.data_ptr(), nm.C, nm.src.NI, nm.C, nm.src.H * nm.src.W, GN_GROUPS, GN_EPS], 'gn.coeffs')
+                self._emit_coeffs(nm, coefA, coefB)
                 gn = [coefA.data_ptr(), coefB.data_ptr(), nm.C]
                 if nm.silu:
                     flags |= _hip.CONV_GN_SILU
@@ -671,10 +693,15 @@ class UNetPlan:
         slot = self._gn_doubles                       # float64 offset of this norm's partials [NI][nblk][32][2]
         self._gn_doubles += NI * nblk * GN_GROUPS * 2
         self._gn_slots += 1
+        pending = None
         if from_conv:
-            self._emit(self.lib.nd_groupnorm_stats_from_partials,
-                       [src.cs[0], src.C, src.cs[1], None if src2 is None else src2.cs[0], 0 if src2 is None else src2.C,
+            # the fold of the partial rows is emitted by the consumer: a convolution that applies the norm in its loader
+            # takes it together with the coefficients (nd_groupnorm_coeffs_from_partials, one launch instead of two)
+            pending = ([src.cs[0], src.C, src.cs[1], None if src2 is None else src2.cs[0], 0 if src2 is None else src2.C,
                         0 if src2 is None else src2.cs[1], ('gnstats', slot), NI, GN_GROUPS], label + '.stats_from_partials')
+            if pool or not _gn_merge_coeffs():
+                self._emit(self.lib.nd_groupnorm_stats_from_partials, *pending)
+                pending = None
         else:
             stats_args = [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], None, 0, ('gnstats', slot), NI, H * W, GN_GROUPS,
                           self.dt]
@@ -688,7 +715,7 @@ class UNetPlan:
             self._emit(self.lib.nd_groupnorm_apply_nhwc, apply_args, label + '.apply')
             return out
         return Normed(src=src, src2=src2, C=C, silu=silu, norm=norm, scale_ptr=scale_ptr, shift_ptr=shift_ptr,
-                      ld_ss=ld_ss, slot=slot, nblk=nblk)
+                      ld_ss=ld_ss, slot=slot, nblk=nblk, pending=pending)
 
     # ------------------------------------------------------------------------------------------------ build
     def _build(self):

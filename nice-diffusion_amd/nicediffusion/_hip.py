@@ -45,6 +45,7 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_groupnorm_channel_partials_nhwc': [_vp, _i, _i, _vp, _i, _i, _i, _vp],
     'nd_groupnorm_coeffs': [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    'nd_groupnorm_coeffs_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     'nd_repack_conv_weight_winograd': [_vp, _vp, _i, _i, _vp],
     'nd_conv_direct_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'nd_repack_conv_weight': [_vp, _vp, _i, _i, _i, _vp],

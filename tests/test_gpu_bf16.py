@@ -370,7 +370,7 @@ def test_bf16_forward_with_epilogue_statistics_matches_statistics_pass(monkeypat
         outs[mode] = m(x, t, y=y).float().cpu()
         plan = next(iter(m._plans.values()))
         used = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_conv3x3_bf16_stats_nhwc')
-        folds = sum(1 for f, _, _ in plan.ops if f.__name__ == 'nd_groupnorm_stats_from_partials')
+        folds = sum(1 for f, _, _ in plan.ops if f.__name__ in ('nd_groupnorm_stats_from_partials', 'nd_groupnorm_coeffs_from_partials'))
         if mode == '0':
             assert used == 0 and folds == 0
         else:

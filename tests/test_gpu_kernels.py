@@ -765,3 +765,41 @@ def test_stride2_conv_via_space_to_depth(B, C, N, H, W):
                                   out.data_ptr(), N, B, H // 2, W // 2, N, 3, 0, -1, None, None, 0, st()))
     assert (from_nhwc(out, B, H // 2, W // 2, N) - ref).abs().max().item() < 2e-4
     assert lib().nd_space_to_depth2_nhwc(xd.data_ptr(), C, s2d.data_ptr(), 4 * C, B, H - 1, W, C, st()) != 0
+
+
+@pytest.mark.parametrize('B,C0,C1,rows0,rows1,HW,adagn', [(3, 64, 0, 5, 0, 256, False), (2, 96, 32, 7, 3, 1024, True),
+                                                            (4, 192, 192, 32, 32, 4096, True), (1, 32, 0, 1, 0, 64, False)])
+def test_groupnorm_coeffs_from_partials_equals_fold_then_coeffs(B, C0, C1, rows0, rows1, HW, adagn):
+    """nd_groupnorm_coeffs_from_partials = nd_groupnorm_stats_from_partials + nd_groupnorm_coeffs, bit for bit (same order of
+    additions, same arithmetic), one- and two-source rows, with and without the AdaGN scale / shift."""
+    C = C0 + C1
+    g = torch.Generator().manual_seed(7)
+    p0 = (torch.rand(B, rows0, 2, C0, generator=g) * 50).to(DEV)
+    p1 = (torch.rand(B, max(rows1, 1), 2, max(C1, 1), generator=g) * 50).to(DEV) if C1 else None
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    sc = (0.3 * torch.randn(B, C, generator=g)).to(DEV) if adagn else None
+    sh = (0.3 * torch.randn(B, C, generator=g)).to(DEV) if adagn else None
+    stats = torch.zeros(B * 32 * 2, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_from_partials(p0.data_ptr(), C0, rows0, _hip.ptr(p1), C1, rows1, stats.data_ptr(), B, 32, st()))
+    a0, b0 = torch.empty(B * C, device=DEV), torch.empty(B * C, device=DEV)
+    _hip.check(lib().nd_groupnorm_coeffs(stats.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), _hip.ptr(sc), _hip.ptr(sh), C,
+                                         a0.data_ptr(), b0.data_ptr(), C, B, C, HW, 32, 1e-5, st()))
+    a1, b1 = torch.full((B * C,), float('nan'), device=DEV), torch.full((B * C,), float('nan'), device=DEV)
+    _hip.check(lib().nd_groupnorm_coeffs_from_partials(p0.data_ptr(), C0, rows0, _hip.ptr(p1), C1, rows1, gamma.data_ptr(),
+                                                       beta.data_ptr(), _hip.ptr(sc), _hip.ptr(sh), C, a1.data_ptr(), b1.data_ptr(),
+                                                       C, B, HW, 32, 1e-5, st()))
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    # against float64 on the host
+    full = torch.cat([p0.sum(1)] + ([p1.sum(1)] if C1 else []), dim=2).double().cpu()      # [B][2][C]
+    gs = full.view(B, 2, 32, C // 32).sum(3)
+    n = (C // 32) * HW
+    mean = gs[:, 0] / n
+    var = (gs[:, 1] / n - mean * mean).clamp(min=0)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    A = rstd.repeat_interleave(C // 32, 1) * gamma.double().cpu()
+    Bc = beta.double().cpu() - mean.repeat_interleave(C // 32, 1) * A
+    if adagn:
+        A, Bc = A * (1 + sc.double().cpu()), Bc * (1 + sc.double().cpu()) + sh.double().cpu()
+    assert (a1.view(B, C).cpu().double() - A).abs().max().item() < 1e-4 * A.abs().max().item()
+    assert (b1.view(B, C).cpu().double() - Bc).abs().max().item() < 1e-4 * max(1.0, Bc.abs().max().item())
+

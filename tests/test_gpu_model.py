@@ -350,7 +350,10 @@ def test_groupnorm_statistics_routes_agree(monkeypatch):
     b = m(x, t, y).clone()
     nb = names()
     # every norm folds partial rows; a tensor is passed over at most once (fewer passes than norms: skip tensors are re-used)
-    assert 'nd_groupnorm_stats_nhwc' not in nb and nb.count('nd_groupnorm_stats_from_partials') == na.count('nd_groupnorm_stats_nhwc')
+    # (a norm applied by a convolution's loader takes its fold and its coefficients in one launch)
+    folds = nb.count('nd_groupnorm_stats_from_partials') + nb.count('nd_groupnorm_coeffs_from_partials')
+    assert 'nd_groupnorm_stats_nhwc' not in nb and folds == na.count('nd_groupnorm_stats_nhwc')
+    assert nb.count('nd_groupnorm_coeffs_from_partials') > 0 and nb.count('nd_groupnorm_coeffs') == 0
     assert nb.count('nd_groupnorm_channel_partials_nhwc') < na.count('nd_groupnorm_stats_nhwc')
     monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '1')
     m._plans = {}
@@ -360,6 +363,15 @@ def test_groupnorm_statistics_routes_agree(monkeypatch):
     m._plans = {}
     tol = 2e-5 * max(1.0, a.abs().max().item())
     assert torch.isfinite(b).all() and (a - b).abs().max().item() < tol and (a - c).abs().max().item() < tol
+    # the merged fold + coefficient launch computes the same bits as the two launches it replaces
+    monkeypatch.setenv('ND_GN_MERGE_COEFFS', '0')
+    m._plans = {}
+    d = m(x, t, y).clone()
+    nd_ = names()
+    monkeypatch.delenv('ND_GN_MERGE_COEFFS')
+    m._plans = {}
+    assert 'nd_groupnorm_coeffs_from_partials' not in nd_ and nd_.count('nd_groupnorm_coeffs') > 0
+    assert torch.equal(b, d)
     assert 'nd_conv3x3_winograd_vstats_nhwc' in nc, 'no conv left statistics behind (the tuner chose other kernels for every conv)'
     b2 = m(x, t, y)
     assert torch.equal(b, b2)          # and the default route is bitwise repeatable (no atomics anywhere)

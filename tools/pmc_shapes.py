@@ -24,7 +24,7 @@ CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino16p_kerne
                 'gemm4_kernel')
 # the other kernel classes of a forward: counters aggregated per kernel name (no per-shape key)
 CLASS_KERNELS = ('attention_kernel', 'attention_bf16_kernel', 'gn_stats_kernel', 'gn_apply_kernel', 'gn_from_partials_kernel',
-                 'gn_coeffs_kernel', 'splitk_reduce_kernel')
+                 'gn_coeffs_kernel', 'gn_coeffs_from_partials_kernel', 'splitk_reduce_kernel')
 OUT_NAME = os.environ.get('ND_PMC_OUT', 'r03_pmc_shapes.json')
 
 
