@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         } else {
                             *reinterpret_cast<bf16x4*>(orow[mi] + ni * 32 + 8 * g4) = o;
                         }
-                        if constexpr (STATS) {      // sums of what was stored: the statistics are those of the bf16 tensor
+                        if constexpr (STATS && !STAGED) {      // sums of what was stored: the statistics are those of the bf16 tensor
                             const f32x4 of = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         }
                     }
                 }
-                if constexpr (STATS) {
+                if constexpr (STATS && !STAGED) {
                     // per-channel sums over this wave's TM x 32 pixels -> row (pixel tile, wave row) of p.chstats (same order of
                     // additions as the general form: mi ascending, then the 32-lane reduction)
                     float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N +
@@ -564,14 +564,50 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         if constexpr (STAGED) {
             // the wave reads its region back row-major: 8 lanes = the 8 slots of one pixel row = 128 contiguous bytes of the output
             __bf16* const obase = static_cast<__bf16*>(p.out) + n0 + wn * 64 + (lane & 7) * 8;
+            // STATS: the same read feeds the statistics -- a lane sees 8 channels of TM*4 pixels (8 values per 16-byte item
+            // instead of 4 per 8-byte store in the register layout, no conversion back from the stored bf16: the bits are the
+            // high half of the float), then the 8 lane groups that hold the same channels are added by three exchanges.
+            // Fixed order: pixels ascending per lane, then lane ^ 8, ^ 16, ^ 32.
+            float sv[8], sq[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sv[c] = sq[c] = 0.f;
 #pragma unroll
             for (int it = 0; it < TM * 4; ++it) {
                 const int pxl = it * 8 + (lane >> 3);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + pxl * 128 + (((lane & 7) ^ (pxl & 7)) << 4));
+                union { f32x4 f; unsigned u[4]; } v;
+                v.f = *reinterpret_cast<const f32x4*>(stg + pxl * 128 + (((lane & 7) ^ (pxl & 7)) << 4));
                 const int m = wm * TM * 32 + pxl;
                 const int oy = oy0 + ((m >> p.twl) & (TH - 1));
                 const int ox = ox0 + (m & (TW - 1));
-                *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v;
+                *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v.f;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {          // dword j = channels 2j (low half), 2j + 1 (high half)
+                        const float x0 = __uint_as_float(v.u[j] << 16), x1 = __uint_as_float(v.u[j] & 0xffff0000u);
+                        sv[2 * j] += x0;
+                        sv[2 * j + 1] += x1;
+                        sq[2 * j] += x0 * x0;
+                        sq[2 * j + 1] += x1 * x1;
+                    }
+                }
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                    for (int d = 8; d <= 32; d <<= 1) {
+                        sv[c] += __shfl_xor(sv[c], d, 64);
+                        sq[c] += __shfl_xor(sq[c], d, 64);
+                    }
+                }
+                if (lane < 8) {
+                    float* cs = p.chstats + ((size_t)img0 * p.cs_rows + (size_t)(ty * p.tiles_x + tx) * WM + wm) * 2 * p.N +
+                                n0 + wn * 64 + lane * 8;
+                    *reinterpret_cast<f32x4*>(cs) = f32x4{sv[0], sv[1], sv[2], sv[3]};
+                    *reinterpret_cast<f32x4*>(cs + 4) = f32x4{sv[4], sv[5], sv[6], sv[7]};
+                    *reinterpret_cast<f32x4*>(cs + p.N) = f32x4{sq[0], sq[1], sq[2], sq[3]};
+                    *reinterpret_cast<f32x4*>(cs + p.N + 4) = f32x4{sq[4], sq[5], sq[6], sq[7]};
+                }
             }
         }
     } else {

@@ -7,6 +7,7 @@ namespace nd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 struct ConvArgsH {
     const __bf16* x0;
