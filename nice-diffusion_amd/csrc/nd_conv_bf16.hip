@@ -1697,6 +1697,8 @@ static const VariantH kVariantsH[] = {
     // GEMM-shaped 1x1, two blocks per CU (nd_gemm_bf16_quad.hip): pixel rows through 4 LDS stages by LDS-DMA, weights
     // global -> VGPR; coded as ldsw = 3
     {1, 4, 4, 2, 3, 0},   // 21: 128 x 256, 4 waves
+    // the same with 128 px x 128 ch per wave: ONE block of four 512-register waves per CU (nd_gemm_bf16_wide.hip); ldsw = 4
+    {2, 2, 4, 4, 4, 0},   // 22: 256 x 256, 4 waves
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
@@ -1769,7 +1771,7 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
         if (!plan_tiles_h(V, taps, pNI, pH, pW, &tp)) continue;
         const long nblk_n = (N + V.bn() - 1) / V.bn();
         const long nblocks = (long)tp.tiles_x * tp.tiles_y * tp.groups * nblk_n;
-        const size_t lds = V.ldsw == 3 ? (size_t)64 * 1024 : V.ldsw == 2 ? (size_t)3 * 48 * 1024 : (V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp));
+        const size_t lds = V.ldsw == 4 ? (size_t)128 * 1024 : V.ldsw == 3 ? (size_t)64 * 1024 : V.ldsw == 2 ? (size_t)3 * 48 * 1024 : (V.ldsw ? lds_bytes_w(V, tp.hp) : lds_bytes_h(taps, tp.hp));
         int per_cu = (int)(160 * 1024 / lds);
         const int by_waves = 8 / (V.nt() / 64) > 0 ? 8 / (V.nt() / 64) : 1;      // two waves per SIMD
         if (per_cu > by_waves) per_cu = by_waves;
@@ -1902,7 +1904,7 @@ extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int k
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
         int p;
-        if (V.ldsw == 3) p = wstream::pad_chunks(wstream::kBf16GemmQAheadSteps, wstream::bf16_steps(1));      // gemm_bf16q_kernel: one chunk
+        if (V.ldsw >= 3) p = wstream::pad_chunks(wstream::kBf16GemmQAheadSteps, wstream::bf16_steps(1));      // gemm_bf16q_kernel: one chunk
         else if (V.ldsw == 2) p = 0;                                                              // gemm_bf16_kernel: real chunks only
         else if (V.ldsw == 1) p = wstream::pad_chunks(wstream::kBf16DmaAheadTaps, taps);           // conv_bf16w_kernel
         else if (V.mf) p = wstream::pad_chunks(wstream::bf16s_ring(V.tn, taps) - 1, wstream::bf16s_steps(taps));
@@ -1925,7 +1927,7 @@ extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int k
 extern "C" const char* nd_conv_bf16_variant_name(int variant) {
     if (variant < 0 || variant >= kNumVariantsH) return "";
     const VariantH& v = kVariantsH[variant];
-    return v.ldsw == 3 ? "nd::gemm_bf16q_kernel" : v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
+    return v.ldsw == 4 ? "nd::gemm_bf16x_kernel" : v.ldsw == 3 ? "nd::gemm_bf16q_kernel" : v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
                                                                                                : "nd::conv_bf16_kernel";
 }
 
@@ -2068,15 +2070,25 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     }
     const int grid = a.mt * a.nt;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (V.ldsw == 3) {
+#if !defined(ND_EXPERIMENTAL_KERNELS)
+    if (V.ldsw == 4) return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
+#endif
+    if (V.ldsw >= 3) {
         ND_REQUIRE(gnA == nullptr && rowbias == nullptr && !a.out_f32 && !a.silu_out && a.ksplit <= 1 && !a.up && !a.res_up, fn,
                    "the two-block GEMM form takes plain 1x1 convolutions with bf16 output only");
-        ND_REQUIRE(M % 128 == 0 && N % 256 == 0 && C0 % 64 == 0 && C1 % 64 == 0, fn,
-                   "the two-block GEMM form needs M % 128 == 0, N % 256 == 0 and whole 64-channel chunks");
+        ND_REQUIRE(M % V.bm() == 0 && N % 256 == 0 && C0 % 64 == 0 && C1 % 64 == 0, fn,
+                   "the two-block GEMM form needs M % 128 == 0 (256 for the wide form), N % 256 == 0 and whole 64-channel chunks");
         ND_REQUIRE((ldo & 7) == 0 && (!residual || (ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0, fn,
                    "the two-block GEMM form needs 16-byte aligned output rows");
         ND_REQUIRE((double)M * ldx0 * 2 < 2147483648.0 && (double)M * (C1 ? ldx1 : 0) * 2 < 2147483648.0, fn,
                    "the two-block GEMM form addresses its inputs with 32-bit buffer offsets (< 2 GiB)");
+        if (V.ldsw == 4) {
+#if defined(ND_EXPERIMENTAL_KERNELS)
+            return launch_gemm_bf16x(a, grid, s);
+#else
+            return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
+#endif
+        }
         return launch_gemm_bf16q(a, grid, s);
     }
     if (V.ldsw == 2) {

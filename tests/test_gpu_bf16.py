@@ -172,8 +172,16 @@ def test_gemm_bf16_two_blocks_per_cu(B, C0, C1, N, H, W, res, pad):
     wd, bd, rd = pack_bf(w), b.to(DEV), (nhwc_bf(r) if res else None)
     ldo = N + pad
     outs = {}
-    for v in (GEMMQ, 20):
+    wide = 22 if (B * H * W) % 256 == 0 else None      # gemm_bf16x_kernel: 256 px x 256 ch, one block of 512-register waves per CU
+    for v in (GEMMQ, 20) + ((wide,) if wide else ()):
         out = torch.zeros(B * H * W * ldo, dtype=BF, device=DEV)
+        if v == wide:       # an experiment kept out of the product build (make EXPERIMENTAL=1)
+            rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(),
+                                         None, 0, _hip.ptr(rd), N if res else 0, out.data_ptr(), ldo, B, H, W, N, 1, 0, v, None, None, 0, st())
+            if rc != 0:
+                assert 'not built' in _hip.last_error()
+                wide = None
+                continue
         _hip.check(lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(),
                                            None, 0, _hip.ptr(rd), N if res else 0, out.data_ptr(), ldo, B, H, W, N, 1, 0, v, None, None, 0, st()),
                    'variant %d' % v)
@@ -183,6 +191,8 @@ def test_gemm_bf16_two_blocks_per_cu(B, C0, C1, N, H, W, res, pad):
         if pad:
             assert not out.view(B, H, W, ldo)[..., N:].any()
     assert torch.equal(outs[GEMMQ], outs[20])
+    if wide:
+        assert lib().nd_conv_bf16_variant_name(wide) == b'nd::gemm_bf16x_kernel' and torch.equal(outs[wide], outs[20])
     # refused, with the reason: fp32 output, SiLU, N not a multiple of 256, M not a multiple of 128, a per-image bias row
     out32 = torch.zeros(B * H * W * ldo, dtype=torch.float32, device=DEV)
     rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(), None, 0,
