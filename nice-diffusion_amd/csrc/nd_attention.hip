@@ -138,10 +138,14 @@ __global__ void __launch_bounds__(WAVES * 64)
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            // the rescale is skipped while no lane's running maximum moved (alpha == 1 exactly: same bits); on the fp32 matrix
+            // pipe every vector instruction saved is matrix time
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+                for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; MFMA step e contracts keys {e-row, e-row + 4}
 #pragma unroll
             for (int e = 0; e < 16; ++e) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ at_bf16x8 at_as_bf16x8(const u32x4& v) {
 
 // HDP: head dim padded to 64 / 128 / 256 (template), hd: actual head dim (multiple of 8, <= HDP)
 template <int HDP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (HDP <= 128 ? 2 : 1))      // hd <= 128: two blocks per CU keep their registers <= 256
     attention_bf16_kernel(const AttnArgsH p) {
     constexpr int NT = 256;
     constexpr int BQ = 128;                // queries per block
@@ -87,47 +87,80 @@ __global__ void __launch_bounds__(256)
     float m_run = -1e30f, l_run = 0.f;
 
     const int ntiles = (p.T + AH_KT - 1) / AH_KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * AH_KT;
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage K (row-major, swizzled) ...
-        for (int it = tid; it < AH_KT * SPR; it += NT) {
+    // K / V tiles are fetched one tile ahead into registers (hd <= 128: 32 registers) and parked in LDS behind the barrier
+    // that ends the previous tile, so a tile's global latency runs under the previous tile's products instead of in
+    // front of its own (round 3: the kernel sat at 0.15 of the matrix pipe with 0.46 of its wave time parked)
+    constexpr bool PREFETCH = (HDP <= 128);
+    constexpr int KI = (AH_KT * SPR + NT - 1) / NT;            // K items (16 bytes) per thread and tile
+    constexpr int VI = ((AH_KT / 4) * SPR + NT - 1) / NT;      // V items (4 keys x 8 d) per thread and tile
+    u32x4 kpre[KI], vpre[VI][4];
+    auto fetch = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int it = tid + i * NT;
             const int row = it / SPR;
             const int sl = it - row * SPR;
             const int key = key0 + row;
-            u32x4 kv = {0u, 0u, 0u, 0u};
-            if (key < p.T && sl * 8 < p.hd)
-                kv = *reinterpret_cast<const u32x4*>(p.qkv + (rowbase + key) * p.ld_qkv + hoff + p.k_off + sl * 8);
-            const int swz = (SPR >= 16) ? (row & 15) : ((row >> 1) & 7);
-            *reinterpret_cast<u32x4*>(Ks + row * (HDP / 2) + ((sl ^ swz) << 2)) = kv;
+            kpre[i] = u32x4{0u, 0u, 0u, 0u};
+            if (it < AH_KT * SPR && key < p.T && sl * 8 < p.hd)
+                kpre[i] = *reinterpret_cast<const u32x4*>(p.qkv + (rowbase + key) * p.ld_qkv + hoff + p.k_off + sl * 8);
         }
-        // ---- ... and V transposed: item = (4 keys, 8 d); dword pairs (key k, k+1) of one d are packed with v_perm
-        for (int it = tid; it < (AH_KT / 4) * SPR; it += NT) {
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int it = tid + i * NT;
             const int kg = it % (AH_KT / 4);
             const int sl = it / (AH_KT / 4);
-            u32x4 w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = key0 + kg * 4 + r;
-                w[r] = u32x4{0u, 0u, 0u, 0u};
-                if (key < p.T && sl * 8 < p.hd)
-                    w[r] = *reinterpret_cast<const u32x4*>(p.qkv + (rowbase + key) * p.ld_qkv + hoff + p.v_off + sl * 8);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int i = e >> 1;
-                u32x2 pk;
-                if (e & 1) {
-                    pk[0] = (w[0][i] >> 16) | (w[1][i] & 0xffff0000u);
-                    pk[1] = (w[2][i] >> 16) | (w[3][i] & 0xffff0000u);
-                } else {
-                    pk[0] = (w[0][i] & 0xffffu) | (w[1][i] << 16);
-                    pk[1] = (w[2][i] & 0xffffu) | (w[3][i] << 16);
-                }
-                *reinterpret_cast<u32x2*>(Vt + (sl * 8 + e) * AH_VLD + kg * 4) = pk;
+                vpre[i][r] = u32x4{0u, 0u, 0u, 0u};
+                if (it < (AH_KT / 4) * SPR && key < p.T && sl * 8 < p.hd)
+                    vpre[i][r] = *reinterpret_cast<const u32x4*>(p.qkv + (rowbase + key) * p.ld_qkv + hoff + p.v_off + sl * 8);
             }
         }
+    };
+    // K row-major (swizzled); V transposed: item = (4 keys, 8 d), dword pairs (key k, k+1) of one d are packed
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int it = tid + i * NT;
+            const int row = it / SPR;
+            const int sl = it - row * SPR;
+            const int swz = (SPR >= 16) ? (row & 15) : ((row >> 1) & 7);
+            if (it < AH_KT * SPR) *reinterpret_cast<u32x4*>(Ks + row * (HDP / 2) + ((sl ^ swz) << 2)) = kpre[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int it = tid + i * NT;
+            const int kg = it % (AH_KT / 4);
+            const int sl = it / (AH_KT / 4);
+            if (it < (AH_KT / 4) * SPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = e >> 1;
+                    u32x2 pk;
+                    if (e & 1) {
+                        pk[0] = (vpre[i][0][j] >> 16) | (vpre[i][1][j] & 0xffff0000u);
+                        pk[1] = (vpre[i][2][j] >> 16) | (vpre[i][3][j] & 0xffff0000u);
+                    } else {
+                        pk[0] = (vpre[i][0][j] & 0xffffu) | (vpre[i][1][j] << 16);
+                        pk[1] = (vpre[i][2][j] & 0xffffu) | (vpre[i][3][j] << 16);
+                    }
+                    *reinterpret_cast<u32x2*>(Vt + (sl * 8 + e) * AH_VLD + kg * 4) = pk;
+                }
+            }
+        }
+    };
+    if constexpr (PREFETCH) fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * AH_KT;
+        __syncthreads();   // previous tile fully consumed
+        if constexpr (!PREFETCH) fetch(key0);
+        park();
         __syncthreads();
+        if constexpr (PREFETCH) {
+            if (kt + 1 < ntiles) fetch(key0 + AH_KT);
+        }
 
 #pragma unroll 1
         for (int sub = 0; sub < AH_KT / 32; ++sub) {
@@ -167,10 +200,13 @@ __global__ void __launch_bounds__(256)
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            // the rescale is skipped while no lane's running maximum moved (alpha == 1 exactly: same bits)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+                for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
             // ---- O^T[d][query] += sum_key V^T[d][key] * P^T[key][query]; k-step s2 covers keys 16*s2 .. +15 of the subtile,
             //      fragment element j <-> key 16*s2 + 8*(j>>2) + 4*lh + (j&3)
 #pragma unroll
