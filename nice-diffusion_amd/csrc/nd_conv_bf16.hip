@@ -1699,6 +1699,8 @@ static const VariantH kVariantsH[] = {
     {1, 4, 4, 2, 3, 0},   // 21: 128 x 256, 4 waves
     // the same with 128 px x 128 ch per wave: ONE block of four 512-register waves per CU (nd_gemm_bf16_wide.hip); ldsw = 4
     {2, 2, 4, 4, 4, 0},   // 22: 256 x 256, 4 waves
+    // narrow outputs (the UNet's last convolution, 256 -> 6 channels): one 32-channel n tile per block instead of 64
+    {4, 1, 1, 1, 0, 0},   // 23: 128 x  32, 4 waves, wave tile 32 px x 32 ch
 };
 static constexpr int kNumVariantsH = sizeof(kVariantsH) / sizeof(kVariantsH[0]);
 
@@ -1833,6 +1835,7 @@ static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream
         case 9: return launch_h<1, 4, 8, 1, TAPS>(a, grid, lds, s);
         case 10: return launch_h<1, 8, 4, 1, TAPS>(a, grid, lds, s);
         case 11: return launch_h<1, 4, 4, 2, TAPS>(a, grid, lds, s);
+        case 23: return launch_h<4, 1, 1, 1, TAPS>(a, grid, lds, s);
         case 14: return launch_s<1, 4, 8, 4, TAPS>(a, grid, lds, s);
         case 15: return launch_s<1, 4, 8, 2, TAPS>(a, grid, lds, s);
         case 16: return launch_s<2, 2, 4, 4, TAPS>(a, grid, lds, s);
@@ -2179,6 +2182,7 @@ extern "C" int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant)
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && variant >= 0 && variant < kNumVariantsH, fn, "bad arguments");
     const VariantH& V = kVariantsH[variant];
     if (V.ldsw || V.mf || (N & 3)) return 0;
+    if (V.wn == 1 && V.tn == 1) return 0;          // the narrow-output form has no statistics instantiation
     TilePlan tp{};
     if (select_variant_h(variant, 9, NI, H, W, N, &tp) < 0 || tp.nibl != 0) return 0;
     return tp.tiles_x * tp.tiles_y * V.wm;
