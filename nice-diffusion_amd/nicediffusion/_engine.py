@@ -674,7 +674,11 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
-        if _gn_partials_enabled(self.bf16):
+        # a concatenation of which ONE half carries epilogue statistics (the skip tensor of a Downsample layer has none): the
+        # other half gets its rows from a pass over that half alone, so the rows the producing conv paid for are used and the
+        # statistics pass does not re-read the half that has them (the tuner credits the '+stats' conv with that pass)
+        mixed = src2 is not None and (src.cs is None) != (src2.cs is None)
+        if _gn_partials_enabled(self.bf16) or mixed:
             # every source that does not carry per-channel partial sums yet gets them from ONE pass over that tensor alone;
             # they stay with the activation (skip tensors are normalised again in the up path, concatenated: no re-read)
             for a in (src, src2):
