@@ -173,6 +173,14 @@ int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1,
                                const void* residual, int ldr, void* out, int ldo,
                                int NI, int H, int W, int N, int flags, int variant,
                                const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream);
+/* The same for a 1x1 convolution on the two-blocks-per-CU GEMM form (variant 21; the attention block's output projection
+ * + residual feeds the next block's GroupNorm, model.py:291,190): rows = H*W / 128 per image (nd_conv_bf16_stats_rows; 0
+ * unless H*W % 128 == 0 and N % 256 == 0); same argument list, rowbias / gnA / gnB must be NULL. */
+int nd_conv1x1_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                               const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                               const void* residual, int ldr, void* out, int ldo,
+                               int NI, int H, int W, int N, int flags, int variant,
+                               const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream);
 /* The same convolution split over K for layers with too few output tiles to fill the chip (8x8 / 16x16 maps): block row s
  * of `splits` computes a range of whole input-channel chunks and leaves raw fp32 partials in `workspace` (splits * NI*H*W * N
  * floats), a second kernel adds them in split order (deterministic) with bias / rowbias / residual / SiLU and writes bf16.

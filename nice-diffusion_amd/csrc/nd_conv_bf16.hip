@@ -2008,8 +2008,14 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     const VariantH& V = kVariantsH[v];
     const bool stats = chstats != nullptr || stats_rows_only;
     if (stats) {
-        ND_REQUIRE(taps == 9 && !V.ldsw && !V.mf, fn, "statistics: 3x3 convolutions by the conv_bf16_kernel variants only");
-        ND_REQUIRE(tp.nibl == 0, fn, "statistics need one image per block (H*W >= pixel tile)");
+        const bool gemmq = taps == 1 && V.ldsw == 3;
+        ND_REQUIRE((taps == 9 && !V.ldsw && !V.mf) || gemmq, fn,
+                   "statistics: 3x3 convolutions by the conv_bf16_kernel variants, 1x1 by the two-block GEMM form only");
+        if (gemmq) {
+            ND_REQUIRE(((long)H * W) % 128 == 0 && N % 256 == 0, fn, "statistics (1x1): H*W % 128 == 0 and N % 256 == 0");
+            if (stats_rows_only) return H * W / 128;
+        }
+        ND_REQUIRE(gemmq || tp.nibl == 0, fn, "statistics need one image per block (H*W >= pixel tile)");
         ND_REQUIRE((N & 3) == 0 && (ldo & 3) == 0 && (!residual || (ldr & 3) == 0) && (!rowbias || (ld_rowbias & 3) == 0) &&
                    !(flags & ND_CONV_OUT_F32), fn, "statistics: N and the strides must be multiples of 4, bf16 output");
         if (stats_rows_only) return tp.tiles_x * tp.tiles_y * V.wm;
@@ -2017,7 +2023,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
 
     ConvArgsH a;
     a.chstats = chstats;
-    a.cs_rows = tp.tiles_x * tp.tiles_y * V.wm;
+    a.cs_rows = (taps == 1 && V.ldsw == 3) ? H * W / 128 : tp.tiles_x * tp.tiles_y * V.wm;
     a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;
     const int nc64 = (C0 + C1 + 63) / 64;
     if (splits > 1) {
@@ -2056,6 +2062,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     a.out_f32 = (flags & ND_CONV_OUT_F32) ? 1 : 0;
     if (a.ksplit > 1) { a.silu_out = 0; a.out_f32 = 1; }
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
+    if (chstats && taps == 1 && V.ldsw == 3) a.gn_hw = H * W;          // statistics rows of the flat GEMM: image = pixel / (H * W)
     size_t lds_gn = 0;
     if (gnA) {
         // one image per block, so that the block's coefficient table in LDS is that image's
@@ -2181,6 +2188,7 @@ extern "C" int nd_conv_bf16_stats_rows(int NI, int H, int W, int N, int variant)
     const char* fn = "nd_conv_bf16_stats_rows";
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && variant >= 0 && variant < kNumVariantsH, fn, "bad arguments");
     const VariantH& V = kVariantsH[variant];
+    if (V.ldsw == 3) return (((long)H * W) % 128 == 0 && N % 256 == 0) ? H * W / 128 : 0;      // gemm_bf16q_kernel (1x1): one row per block
     if (V.ldsw || V.mf || (N & 3)) return 0;
     if (V.wn == 1 && V.tn == 1) return 0;          // the narrow-output form has no statistics instantiation
     TilePlan tp{};
@@ -2198,3 +2206,15 @@ extern "C" int nd_conv3x3_bf16_stats_nhwc(const void* x0, int C0, int ldx0, cons
     return conv_bf16_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
                           NI, H, W, N, 3, flags, variant, gnA, gnB, ld_gn, chstats, false, stream);
 }
+
+extern "C" int nd_conv1x1_bf16_stats_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                          const void* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                          const void* residual, int ldr, void* out, int ldo,
+                                          int NI, int H, int W, int N, int flags, int variant,
+                                          const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream) {
+    const char* fn = "nd_conv1x1_bf16_stats_nhwc";
+    ND_REQUIRE(chstats != nullptr && variant >= 0, fn, "chstats is null / the tile variant must be named");
+    return conv_bf16_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
+                          NI, H, W, N, 1, flags, variant, gnA, gnB, ld_gn, chstats, false, stream);
+}
+

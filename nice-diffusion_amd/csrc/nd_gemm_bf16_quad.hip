@@ -18,7 +18,8 @@
 //            so that k-step 3 can already read the next stage).  Every k-step's weight wait is the same vmcnt(12).
 //   epilogue the compact staged form of conv_bf16_kernel: wave-private [128 px][128 B] LDS region, 16-byte stores, 8 lanes =
 //            one cache line.
-// Host-checked: M % 128 == 0, N % 256 == 0, C0 and C1 multiples of 64, tensors < 2 GiB, bf16 output, no SiLU / fused GroupNorm.
+// Host-checked: M % 128 == 0, N % 256 == 0, C0 and C1 multiples of 64, tensors < 2 GiB, bf16 output, no SiLU / fused GroupNorm;
+// with statistics also H * W % 128 == 0 (a block's 128 pixels belong to one image).
 #include "nd_conv_bf16_args.h"
 #include <type_traits>
 
@@ -27,6 +28,7 @@ namespace nd {
 static_assert(wstream::pad_chunks(wstream::kBf16GemmQAheadSteps, wstream::bf16_steps(1)) <= wstream::kBf16PadChunks,
               "weight read-ahead exceeds the packer's zero padding");
 
+template <bool STATS>      // STATS: also leave the per-channel partial statistics of the output behind (p.chstats, one row per block)
 __global__ void __launch_bounds__(256, 2)
     gemm_bf16q_kernel(const ConvArgsH p) {
     constexpr int BM = 128, BN = 256, TM = 4, TN = 2;
@@ -218,20 +220,62 @@ __global__ void __launch_bounds__(256, 2)
     if (p.res) rows(std::true_type{});
     else rows(std::false_type{});
     __bf16* const obase = static_cast<__bf16*>(p.out) + n0 + wave * 64 + (lane & 7) * 8;
+    // STATS (the attention block's output feeds the next block's GroupNorm, model.py:291,190): the drain's reads also feed
+    // the per-channel sums of what was stored, exactly as in conv_bf16_kernel -- pixels ascending per lane, then the lane
+    // groups that hold the same 8 channels by three exchanges; row = this block's 128 pixels of its image (gn_hw = H * W)
+    float sv[8], sq[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sv[c] = sq[c] = 0.f;
 #pragma unroll
     for (int it = 0; it < TM * 4; ++it) {
         const int pxl = it * 8 + (lane >> 3);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + pxl * 128 + (((lane & 7) ^ (pxl & 7)) << 4));
-        *reinterpret_cast<f32x4*>(obase + (size_t)(m0 + pxl) * p.ldo) = v;
+        union { f32x4 f; unsigned u[4]; } v;
+        v.f = *reinterpret_cast<const f32x4*>(stg + pxl * 128 + (((lane & 7) ^ (pxl & 7)) << 4));
+        *reinterpret_cast<f32x4*>(obase + (size_t)(m0 + pxl) * p.ldo) = v.f;
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = __uint_as_float(v.u[j] << 16), x1 = __uint_as_float(v.u[j] & 0xffff0000u);
+                sv[2 * j] += x0;
+                sv[2 * j + 1] += x1;
+                sq[2 * j] += x0 * x0;
+                sq[2 * j + 1] += x1 * x1;
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+            for (int d = 8; d <= 32; d <<= 1) {
+                sv[c] += __shfl_xor(sv[c], d, 64);
+                sq[c] += __shfl_xor(sq[c], d, 64);
+            }
+        }
+        if (lane < 8) {
+            const int img = m0 / p.gn_hw, row = (m0 - img * p.gn_hw) >> 7;
+            float* cs = p.chstats + ((size_t)img * p.cs_rows + row) * 2 * p.N + n0 + wave * 64 + lane * 8;
+            *reinterpret_cast<f32x4*>(cs) = f32x4{sv[0], sv[1], sv[2], sv[3]};
+            *reinterpret_cast<f32x4*>(cs + 4) = f32x4{sv[4], sv[5], sv[6], sv[7]};
+            *reinterpret_cast<f32x4*>(cs + p.N) = f32x4{sq[0], sq[1], sq[2], sq[3]};
+            *reinterpret_cast<f32x4*>(cs + p.N + 4) = f32x4{sq[4], sq[5], sq[6], sq[7]};
+        }
     }
 }
 
 int launch_gemm_bf16q(const ConvArgsH& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)64 * 1024;
-    auto kern = gemm_bf16q_kernel;
-    static bool attr_set[kMaxDevices] = {};
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    if (a.chstats) {
+        auto kern = gemm_bf16q_kernel<true>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        auto kern = gemm_bf16q_kernel<false>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    }
     return check_launch("nd_conv_bf16_nhwc");
 }
 

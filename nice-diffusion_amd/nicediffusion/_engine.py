@@ -428,7 +428,9 @@ class UNetPlan:
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N, ksize, flags]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = ('bf16', NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
-        stats_ok = want_stats and _bf16_epilogue_stats() and ksize == 3 and out.bf16 and out.ld == N
+        # (1x1: the two-blocks-per-CU GEMM form writes the rows too -- the attention block's output projection)
+        stats_ok = want_stats and _bf16_epilogue_stats() and out.bf16 and out.ld == N and \
+            (ksize == 3 or (rowbias is None and gn[0] is None))
         if stats_ok:
             key = key + ('stats',)
         var, mode = self._pick_bf16(key, fl, head, gn, weight, pad_c_to, W_SLOT, out if stats_ok else None)
@@ -453,7 +455,8 @@ class UNetPlan:
             ph = ('chpart', self._cs_floats)
             out.cs = (ph, rows)
             self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
-            self._emit(self.lib.nd_conv3x3_bf16_stats_nhwc, head[:-2] + [flags, var] + gn + [ph], label, flops=fl,
+            self._emit(self.lib.nd_conv3x3_bf16_stats_nhwc if ksize == 3 else self.lib.nd_conv1x1_bf16_stats_nhwc,
+                       head[:-2] + [flags, var] + gn + [ph], label, flops=fl,
                        variant=('bf16', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         else:
             self._emit(self.lib.nd_conv_bf16_nhwc, head + [var] + gn, label, flops=fl, variant=('bf16', var), ksize=ksize,
@@ -483,6 +486,8 @@ class UNetPlan:
             return c[1], ('stats' if c[0] == 'bf16+stats' else 'plain')
         stream = self._stream()
         fn = self.lib.nd_conv_bf16_nhwc
+        ksize_ = head[-2]
+        stats_fn = self.lib.nd_conv3x3_bf16_stats_nhwc if ksize_ == 3 else self.lib.nd_conv1x1_bf16_stats_nhwc
 
         def measure(f, args):
             if not _CLOCK_SETTLED[0]:
@@ -528,8 +533,8 @@ class UNetPlan:
                     if scratch is None or scratch.numel() < need:
                         scratch = torch.empty(need, dtype=torch.float32, device=self.device)
                     sargs = h[:-2] + [h[-1], v] + gn + [scratch.data_ptr()]
-                    if self.lib.nd_conv3x3_bf16_stats_nhwc(*sargs, stream) == 0:
-                        t = measure(self.lib.nd_conv3x3_bf16_stats_nhwc, sargs)
+                    if stats_fn(*sargs, stream) == 0:
+                        t = measure(stats_fn, sargs)
                         if sbest_ms is None or t < sbest_ms:
                             sbest, sbest_ms = v, t
         if best_ms is None:
@@ -930,7 +935,7 @@ class UNetPlan:
         self.conv_flops['attention'] = self.conv_flops.get('attention', 0) + 4 * NI * nh * T * T * hd
         self._release(qkv)
         out = self.conv(a, ab.proj_out.weight, ab.proj_out.bias.detach().data_ptr(), C, 1,
-                        residual=x, label='conv1x1')
+                        residual=x, label='conv1x1', want_stats=True)
         self._release(a)
         return out
 

@@ -56,6 +56,8 @@ SIGNATURES = {
                           _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_conv3x3_bf16_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                    _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    'nd_conv1x1_bf16_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                   _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     'nd_conv_bf16_stats_rows': [_i, _i, _i, _i, _i],
     'nd_conv_bf16_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

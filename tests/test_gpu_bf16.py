@@ -193,6 +193,26 @@ def test_gemm_bf16_two_blocks_per_cu(B, C0, C1, N, H, W, res, pad):
     assert torch.equal(outs[GEMMQ], outs[20])
     if wide:
         assert lib().nd_conv_bf16_variant_name(wide) == b'nd::gemm_bf16x_kernel' and torch.equal(outs[wide], outs[20])
+    # the same launch leaving the per-channel partial statistics of its output behind (nd_conv1x1_bf16_stats_nhwc: the attention
+    # block's output projection feeds the next GroupNorm): same output bits, rows = exact sums of the stored values
+    rows = lib().nd_conv_bf16_stats_rows(B, H, W, N, GEMMQ)
+    if pad == 0:
+        assert rows == (H * W // 128 if (H * W) % 128 == 0 else 0)
+    if rows > 0 and pad == 0:
+        out_s = torch.zeros(B * H * W * N, dtype=BF, device=DEV)
+        ps = torch.full((B * rows * 2 * N,), float('nan'), dtype=torch.float32, device=DEV)
+        _hip.check(lib().nd_conv1x1_bf16_stats_nhwc(xad.data_ptr(), C0, C0, _hip.ptr(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                                    _hip.ptr(rd), N if res else 0, out_s.data_ptr(), N, B, H, W, N, 0, GEMMQ, None, None, 0,
+                                                    ps.data_ptr(), st()))
+        assert torch.equal(out_s, outs[GEMMQ]) and not torch.isnan(ps).any()
+        o = out_s.view(B, H * W, N).double()
+        pp = ps.view(B, rows, 2, N).double().sum(1)
+        assert (pp[:, 0] - o.sum(1)).abs().max().item() <= 1e-5 * max(1.0, o.abs().sum(1).max().item())
+        assert (pp[:, 1] - (o * o).sum(1)).abs().max().item() <= 1e-5 * (o * o).sum(1).max().item()
+        # a variant that cannot is refused by name
+        assert lib().nd_conv1x1_bf16_stats_nhwc(xad.data_ptr(), C0, C0, _hip.ptr(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0,
+                                                _hip.ptr(rd), N if res else 0, out_s.data_ptr(), N, B, H, W, N, 0, 20, None, None, 0,
+                                                ps.data_ptr(), st()) != 0
     # refused, with the reason: fp32 output, SiLU, N not a multiple of 256, M not a multiple of 128, a per-image bias row
     out32 = torch.zeros(B * H * W * ldo, dtype=torch.float32, device=DEV)
     rc = lib().nd_conv_bf16_nhwc(xad.data_ptr(), C0, C0 + pad, _hip.ptr(xbd), C1, C1 + pad if C1 else 0, wd.data_ptr(), bd.data_ptr(), None, 0,
