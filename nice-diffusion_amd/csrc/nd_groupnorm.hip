@@ -360,6 +360,32 @@ static int check_src(const char* fn, const void* x0, int C0, int ldx0, const voi
     return ND_OK;
 }
 
+// Thread t's share of the partial rows of one group: items (row r, channel c_lo + j), j < n, in the order t, t + 128, ...
+// -- four at a time into four accumulators that are added pairwise at the end (four independent loads in flight: the
+// loop is latency-bound, 512 rows x 8 channels per block at 256x256), a fixed order shared by gn_from_partials_kernel and
+// gn_coeffs_from_partials_kernel so that both produce the same float64 sums.
+__device__ __forceinline__ void gn_fold_rows(const float* p, int C, int rows, int n, int c_lo, int img, int t, double& a, double& b) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    const int total = rows * n;
+    const float* base = p + ((size_t)img * rows * 2) * C + c_lo;
+    auto item = [&](int i, double& sa, double& sb) {
+        if (i < total) {
+            const int r = i / n, cc = i - r * n;
+            const float* q = base + (size_t)r * 2 * C + cc;
+            sa += (double)q[0];
+            sb += (double)q[C];
+        }
+    };
+    for (int i = t; i < total; i += 512) {
+        item(i, a0, b0);
+        item(i + 128, a1, b1);
+        item(i + 256, a2, b2);
+        item(i + 384, a3, b3);
+    }
+    a += (a0 + a1) + (a2 + a3);
+    b += (b0 + b1) + (b2 + b3);
+}
+
 // partial rows [img][row][0|1][C] (sum | sum of squares per channel) of a (two-source) tensor -> per-(image, group) sums
 // in float64, written (not added) in a fixed order: one block per (group, image); thread t adds the (row, channel) items
 // t, t + 128, ... of the group in float64, the 128 thread sums are added by a fixed tree in LDS.
@@ -374,19 +400,9 @@ __global__ void __launch_bounds__(128)
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     const int n0 = c_lo < C0 ? ((c_hi < C0 ? c_hi : C0) - c_lo) : 0;      // channels c_lo .. c_lo + n0 - 1 of source 0
     const int n1 = cpg - n0;                                              // then n1 channels of source 1
-    for (int i = t; i < rows0 * n0; i += 128) {
-        const int r = i / n0, cc = c_lo + (i - r * n0);
-        const float* q = p0 + (((size_t)img * rows0 + r) * 2) * C0 + cc;
-        a += (double)q[0];
-        b += (double)q[C0];
-    }
     const int c1_lo = (c_lo > C0 ? c_lo : C0) - C0;
-    for (int i = t; i < rows1 * n1; i += 128) {
-        const int r = i / n1, cc = c1_lo + (i - r * n1);
-        const float* q = p1 + (((size_t)img * rows1 + r) * 2) * C1 + cc;
-        a += (double)q[0];
-        b += (double)q[C1];
-    }
+    if (n0 > 0) gn_fold_rows(p0, C0, rows0, n0, c_lo, img, t, a, b);
+    if (n1 > 0) gn_fold_rows(p1, C1, rows1, n1, c1_lo, img, t, a, b);
     red[0][t] = a;
     red[1][t] = b;
     __syncthreads();
@@ -421,19 +437,9 @@ __global__ void __launch_bounds__(128)
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     const int n0 = c_lo < C0 ? ((c_hi < C0 ? c_hi : C0) - c_lo) : 0;
     const int n1 = cpg - n0;
-    for (int i = t; i < rows0 * n0; i += 128) {
-        const int r = i / n0, cc = c_lo + (i - r * n0);
-        const float* q = p0 + (((size_t)img * rows0 + r) * 2) * C0 + cc;
-        a += (double)q[0];
-        b += (double)q[C0];
-    }
     const int c1_lo = (c_lo > C0 ? c_lo : C0) - C0;
-    for (int i = t; i < rows1 * n1; i += 128) {
-        const int r = i / n1, cc = c1_lo + (i - r * n1);
-        const float* q = p1 + (((size_t)img * rows1 + r) * 2) * C1 + cc;
-        a += (double)q[0];
-        b += (double)q[C1];
-    }
+    if (n0 > 0) gn_fold_rows(p0, C0, rows0, n0, c_lo, img, t, a, b);
+    if (n1 > 0) gn_fold_rows(p1, C1, rows1, n1, c1_lo, img, t, a, b);
     red[0][t] = a;
     red[1][t] = b;
     __syncthreads();
