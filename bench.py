@@ -363,8 +363,17 @@ def main():
         # rank 0 measures the tile variants, every rank runs its choices (identical kernels on every GPU)
         from nicediffusion.parallel import tune_on_rank0
         tune_on_rank0(model, (2 if wl['cfg'] is not None else 1) * B)
-    for _ in range(args.warmup):
+    def progress(what, i, n):
+        # a line per pass on stderr (rank 0): long runs (the driver's 25 chains of ~17 s) stay visibly alive; no device
+        # synchronisation -- the line marks that the pass has been ENQUEUED
+        if rank == 0:
+            print('bench: {} pass {}/{} enqueued at {:.1f} s'.format(what, i + 1, n, time.perf_counter() - t_start),
+                  file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    for i in range(args.warmup):
         one_pass()
+        progress('warm-up', i, args.warmup)
     barrier()
     # per-pass marks for the median: events on the launch stream, no synchronisation inside the timed region
     marks = [] if stub else [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -375,6 +384,7 @@ def main():
         out = one_pass()
         if marks:
             marks[i + 1].record()
+        progress('timed', i, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     pass_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
