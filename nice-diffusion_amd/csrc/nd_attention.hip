@@ -120,11 +120,19 @@ __global__ void __launch_bounds__(WAVES * 64)
             }
             // ---- online softmax for this lane's query; register e <-> key kbase + (e&3) + 8*(e>>2) + 4*lh
             float mx = -1e30f;
+            if (kbase + 32 <= p.T) {          // whole sub-tile inside the sequence (always, when T % 32 == 0): no masks
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                s[e] = (key < p.T) ? s[e] * p.scale_log2e : -1e30f;
-                mx = fmaxf(mx, s[e]);
+                for (int e = 0; e < 16; ++e) {
+                    s[e] *= p.scale_log2e;
+                    mx = fmaxf(mx, s[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    s[e] = (key < p.T) ? s[e] * p.scale_log2e : -1e30f;
+                    mx = fmaxf(mx, s[e]);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
