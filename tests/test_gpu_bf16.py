@@ -223,6 +223,26 @@ def test_gemm_bf16_two_blocks_per_cu(B, C0, C1, N, H, W, res, pad):
     assert rc != 0 and 'two-block GEMM form' in _hip.last_error()
 
 
+def test_gemm_bf16_two_blocks_per_cu_run_to_run():
+    """gemm_bf16q_kernel issues its operand loads as inline ISA with hand-counted waits: a register that the compiler re-used
+    while a load into it was still in flight would show as run-to-run differences (the failure conv_wino4_kernel had in this
+    round before its fragments were tied to the final wait).  Short K, several n blocks, residual, many launches back to
+    back on a busy chip: every output must equal the 3-stage form's, bit for bit, every time."""
+    for (B, C, N, H, W) in ((8, 64, 768, 16, 16), (4, 128, 256, 32, 32), (2, 512, 1536, 32, 32)):
+        x, w, b, r = rnd(B, C, H, W, seed=11), rnd(N, C, seed=12, scale=0.05), rnd(N, seed=13), rnd(B, N, H, W, seed=14)
+        xd, wd, bd, rd = nhwc_bf(x), pack_bf(w), b.to(DEV), nhwc_bf(r)
+        ref = torch.zeros(B * H * W * N, dtype=BF, device=DEV)
+        _hip.check(lib().nd_conv_bf16_nhwc(xd.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, rd.data_ptr(), N,
+                                           ref.data_ptr(), N, B, H, W, N, 1, 0, 20, None, None, 0, st()))
+        outs = [torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV) for _ in range(24)]
+        for o in outs:
+            _hip.check(lib().nd_conv_bf16_nhwc(xd.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0, rd.data_ptr(), N,
+                                               o.data_ptr(), N, B, H, W, N, 1, 0, GEMMQ, None, None, 0, st()))
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, ref), (B, C, N, i)
+
+
 def test_conv_bf16_fused_options():
     """Two-source input (torch.cat), per-image bias, residual, nearest-2x input / residual, SiLU -- the options of the
     fp32 kernel (model.py:474, :205, :211, :77-79)."""
