@@ -66,7 +66,10 @@ __device__ __forceinline__ void split_k_args(ConvArgsH& p, int s, int taps) {
 }
 
 
-template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
+// K16: the input has <= 16 channels (the UNet's first convolution: 3 image channels padded to 8), so only the first
+// k-step of every tap holds anything -- the other three (zero activations times zero-padded weights) are skipped:
+// 9 instead of 36 k-steps, the same bits.
+template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false, bool K16 = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
     conv_bf16_kernel(const ConvArgsH pin) {
     ConvArgsH p = pin;
@@ -249,15 +252,16 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     f32x4 a_fr[TM], b_fr[RING][TN];
     // the packed buffer ends in wstream::kBf16PadChunks zero chunks; the static_assert above is what lets the stream run
     // BDIST fragments past the last real one (split-K shifts the pointer by whole chunks and ends on a chunk boundary)
+    static_assert(!K16 || (TAPS == 9 && wstream::pad_chunks(4 * BDIST, STEPS) <= wstream::kBf16PadChunks), "K16: 3x3 only; read-ahead of BDIST taps");
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #if !defined(ND_HABL_NOB)        // timing-only ablation: weight fragments stay whatever the registers hold
             dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
 #endif
-            bp[ni] += 512;
+            bp[ni] += K16 ? 4 * 512 : 512;          // K16: the tap's k-steps 1..3 are skipped
         }
-        if (++ld_in_c64 == STEPS) {
+        if (++ld_in_c64 == (K16 ? TAPS : STEPS)) {
             ld_in_c64 = 0;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) bp[ni] += c64_jump;
@@ -336,8 +340,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                     const int tapoff = dy * HW + dx;
                     const int tapoff_n = (dx < 2) ? tapoff + 1 : ((dy < 2) ? (dy + 1) * HW : 0);
 #pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        const int st = dx * 4 + kc;                 // 0 .. 11, compile-time: ring slots are static
+                    for (int kc = 0; kc < (K16 ? 1 : 4); ++kc) {
+                        const int st = K16 ? dx : dx * 4 + kc;      // 0 .. 11 (K16: 0 .. 2), compile-time: ring slots are static
                         advance_b(b_fr[(st + BDIST) % RING]);
                         if (dx == 0 && kc == 0) {
 #pragma unroll
@@ -345,8 +349,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                         }
                         int noff[TM];
                         {
-                            const int nslot = (((kc + 1) & 3) << 1) | lh;
-                            const int toff = (kc == 3) ? tapoff_n : tapoff;
+                            const int nslot = K16 ? lh : ((((kc + 1) & 3) << 1) | lh);
+                            const int toff = (K16 || kc == 3) ? tapoff_n : tapoff;
 #pragma unroll
                             for (int mi = 0; mi < TM; ++mi) {
                                 const int hp = a_hp[mi] + toff;     // (after the last step of a chunk this reads stale but
@@ -1791,9 +1795,9 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
     return best_v;
 }
 
-template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false>
+template <int WM, int WN, int TM, int TN, int TAPS, bool STATS = false, bool K16 = false>
 static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS, STATS>;
+    auto kern = conv_bf16_kernel<WM, WN, TM, TN, TAPS, STATS, K16>;
     static bool attr_set[kMaxDevices] = {};
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WM * WN * 64), lds, s, a);
@@ -1834,7 +1838,11 @@ static int dispatch_h(int v, const ConvArgsH& a, int grid, size_t lds, hipStream
         case 8: return launch_h<1, 8, 8, 1, TAPS>(a, grid, lds, s);
         case 9: return launch_h<1, 4, 8, 1, TAPS>(a, grid, lds, s);
         case 10: return launch_h<1, 8, 4, 1, TAPS>(a, grid, lds, s);
-        case 11: return launch_h<1, 4, 4, 2, TAPS>(a, grid, lds, s);
+        case 11:
+            if constexpr (TAPS == 9) {
+                if (a.C0 + a.C1 <= 16 && a.ksplit <= 1) return launch_h<1, 4, 4, 2, 9, false, true>(a, grid, lds, s);
+            }
+            return launch_h<1, 4, 4, 2, TAPS>(a, grid, lds, s);
         case 23: return launch_h<4, 1, 1, 1, TAPS>(a, grid, lds, s);
         case 14: return launch_s<1, 4, 8, 4, TAPS>(a, grid, lds, s);
         case 15: return launch_s<1, 4, 8, 2, TAPS>(a, grid, lds, s);
@@ -1861,7 +1869,9 @@ static int dispatch_h_stats(int v, const ConvArgsH& a, int grid, size_t lds, hip
         case 8: return launch_h<1, 8, 8, 1, 9, true>(a, grid, lds, s);
         case 9: return launch_h<1, 4, 8, 1, 9, true>(a, grid, lds, s);
         case 10: return launch_h<1, 8, 4, 1, 9, true>(a, grid, lds, s);
-        case 11: return launch_h<1, 4, 4, 2, 9, true>(a, grid, lds, s);
+        case 11:
+            if (a.C0 + a.C1 <= 16) return launch_h<1, 4, 4, 2, 9, true, true>(a, grid, lds, s);
+            return launch_h<1, 4, 4, 2, 9, true>(a, grid, lds, s);
     }
     set_error("nd_conv_bf16_stats_nhwc: variant %d cannot leave statistics behind", v);
     return ND_E_ARG;

@@ -339,7 +339,9 @@ def test_conv_bf16_fused_groupnorm(ksize, silu):
     (1, 64, 0, 64, 64, 64, 'gn'), (2, 64, 0, 96, 16, 16, 'res_up'), (2, 32, 0, 48, 32, 32, 'up'),
     # whole 256-channel n blocks on full tiles: the compact staged epilogue (statistics formed while draining the LDS region)
     (2, 64, 0, 256, 32, 32, ''), (1, 128, 64, 512, 16, 16, 'rowbias,residual'), (2, 64, 0, 256, 16, 16, 'gn'),
-    (1, 64, 0, 256, 32, 32, 'res_up')])
+    (1, 64, 0, 256, 32, 32, 'res_up'),
+    # <= 16 input channels (the UNet's first convolution): variant 11 skips the three empty k-steps of every tap
+    (2, 8, 0, 256, 32, 32, ''), (1, 8, 8, 256, 16, 16, 'rowbias')])
 def test_conv3x3_bf16_epilogue_statistics(B, C0, C1, N, H, W, opts):
     """nd_conv3x3_bf16_stats_nhwc: bit-identical output to nd_conv_bf16_nhwc with the same variant, plus partial per-channel
     sums / sums of squares of the bf16 values it stored; nd_groupnorm_stats_from_partials folds them into what the
