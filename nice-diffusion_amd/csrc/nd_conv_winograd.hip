@@ -207,7 +207,9 @@ __global__ void __launch_bounds__(256 * WNT, (WNT == 2) ? 2 : 3)
         const float* hbuf = smem + (ch & 1) * (HP * ROWF);
         const bool halo_next = (ch + 1) < nchunks;
         load_gn(ch + 1, gA, gB);                 // every halo fetch of this iteration is for chunk ch + 1
-        int nvalid = (p.NC32 - ch * NSUB) * 4;          // k-steps of this chunk that hold real channels
+        // k-steps (8 channels) of this chunk that hold real channels: the rest -- zero activations times zero-padded weights --
+        // is skipped (only ever in the last chunk; the UNet's first convolution, 3 image channels padded to 4, runs 1 of 4)
+        int nvalid = (p.C0 + p.C1 - ch * (32 * NSUB) + 7) >> 3;
         if (nvalid > NSTEP) nvalid = NSTEP;
         f32x4 phb[HB];
         if constexpr (APF) read_patch(hbuf, 0, 0, pa[0], pb[0]);
