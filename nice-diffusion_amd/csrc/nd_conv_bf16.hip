@@ -475,8 +475,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // general form.
     constexpr bool STAGED = (TN == 2);
     // staged stores: region of this wave = [TM*32 pixels][128 bytes], 16-byte slot s of pixel row r at slot s ^ (r & 7)
-    const bool common = vec_ok && (n0 + BN <= p.N) && p.nibl == 0 && !p.silu_out && !p.out_f32 && img0 < p.NI &&
-                        oy0 + TH <= p.H && ox0 + TW <= p.W && (!STAGED || p.coal != 0);
+    // (several images per block -- the 8x8 maps -- take it too where no statistics are written: the image is per lane then)
+    const bool common = vec_ok && (n0 + BN <= p.N) && (p.nibl == 0 || !STATS) && !p.silu_out && !p.out_f32 &&
+                        img0 + (1 << p.nibl) <= p.NI && oy0 + TH <= p.H && ox0 + TW <= p.W && (!STAGED || p.coal != 0);
     char* const stg = reinterpret_cast<char*>(smem) + wave * (TM * 32 * 128);
     if (common) {
         // per pixel row of the wave tile: output row, residual row (the whole tile lies inside the image: no masks)
@@ -487,11 +488,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             const int m = (wm * TM + mi) * 32 + l31;
             const int oy = oy0 + ((m >> p.twl) & (TH - 1));
             const int ox = ox0 + (m & (TW - 1));
-            const size_t opix = (size_t)(img0 * p.H + oy) * p.W + ox;
+            const int img = img0 + (m >> (p.thl + p.twl));
+            const size_t opix = (size_t)(img * p.H + oy) * p.W + ox;
             orow[mi] = static_cast<__bf16*>(p.out) + opix * p.ldo + n0 + wn * (TN * 32) + 4 * lh;
             rrow[mi] = nullptr;
             if (p.res) {
-                const size_t rp = p.res_up ? ((size_t)(img0 * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
+                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
                 rrow[mi] = p.res + rp * p.ldr + n0 + wn * (TN * 32) + 4 * lh;
             }
         }
@@ -517,7 +519,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                     for (int g4 = 0; g4 < 4; ++g4) {
                         f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2], acc[mi][ni][4 * g4 + 3]};
                         v += bv[g4];                          // +0 when there is no bias
-                        if constexpr (decltype(has_rb)::value) v += rbv[g4];
+                        if constexpr (decltype(has_rb)::value) {
+                            if (p.nibl == 0) {
+                                v += rbv[g4];
+                            } else {          // several images per block: the timestep row is this lane's image's
+                                const int img = img0 + (((wm * TM + mi) * 32 + l31) >> (p.thl + p.twl));
+                                v += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + n0 + wn * (TN * 32) + 4 * lh +
+                                                                     ni * 32 + 8 * g4);
+                            }
+                        }
                         if constexpr (decltype(has_res)::value) {
                             const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow[mi] + ni * 32 + 8 * g4);
 #pragma unroll
@@ -583,7 +593,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 const int m = wm * TM * 32 + pxl;
                 const int oy = oy0 + ((m >> p.twl) & (TH - 1));
                 const int ox = ox0 + (m & (TW - 1));
-                *reinterpret_cast<f32x4*>(obase + ((size_t)(img0 * p.H + oy) * p.W + ox) * p.ldo) = v.f;
+                const int img = img0 + (m >> (p.thl + p.twl));
+                *reinterpret_cast<f32x4*>(obase + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo) = v.f;
                 if constexpr (STATS) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {          // dword j = channels 2j (low half), 2j + 1 (high half)

@@ -108,7 +108,7 @@ def test_repack_conv_weight_bf16(N, C, k):
 
 CONV_CASES = [  # B, Cin, Cout, H, W
     (2, 64, 96, 16, 16), (3, 40, 72, 12, 20), (8, 128, 128, 8, 8), (1, 64, 64, 64, 64), (2, 192, 40, 7, 7),
-    (1, 8, 64, 32, 32),
+    (1, 8, 64, 32, 32), (4, 64, 256, 8, 8),
 ]
 
 
@@ -145,6 +145,28 @@ def test_conv_bf16_all_variants(B, Cin, Cout, H, W, ksize):
             else:
                 assert (err <= _tol_bf16(ref)).all(), (v, err.max().item())
     assert ran >= 4
+
+
+@pytest.mark.parametrize('B,C,N,H,W', [(6, 64, 256, 8, 8), (4, 128, 512, 8, 8), (3, 64, 256, 4, 8)])
+def test_conv_bf16_several_images_per_block_with_row_bias_and_residual(B, C, N, H, W):
+    """8x8 maps put two (or more) images into one 128-pixel block: the compact epilogue then takes the per-image timestep row
+    and the output / residual rows per lane (model.py:205,211 on the 8x8 levels of configs[3], [4])."""
+    x, w = rnd(B, C, H, W, seed=1), rnd(N, C, 3, 3, seed=2, scale=0.05)
+    b, rb, res = rnd(N, seed=3), rnd(B, N, seed=4), rnd(B, N, H, W, seed=5)
+    ref = (F.conv2d(q(x).double(), q(w).double(), b.double(), padding=1) + rb.double()[:, :, None, None] + q(res).double()).float()
+    xd, wd, bd, rbd, resd = nhwc_bf(x), pack_bf(w), b.to(DEV), rb.to(DEV), nhwc_bf(res)
+    outs = []
+    for v in (11, 0, 4, 3, -1):
+        out = torch.full((B * H * W * N,), float('nan'), dtype=BF, device=DEV)
+        rc = lib().nd_conv_bf16_nhwc(xd.data_ptr(), C, C, None, 0, 0, wd.data_ptr(), bd.data_ptr(), rbd.data_ptr(), N, resd.data_ptr(), N,
+                                     out.data_ptr(), N, B, H, W, N, 3, 0, v, None, None, 0, st())
+        if rc != 0:
+            assert 'no tile variant fits' in _hip.last_error()
+            continue
+        err = (from_nhwc(out, B, H, W, N) - ref).abs()
+        assert (err <= _tol_bf16(ref)).all(), (v, err.max().item())
+        outs.append(out)
+    assert len(outs) >= 3 and all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 GEMMQ = 21      # gemm_bf16q_kernel: 128 px x 256 ch, two blocks per CU (nd_gemm_bf16_quad.hip)
