@@ -362,8 +362,9 @@ static int check_src(const char* fn, const void* x0, int C0, int ldx0, const voi
 
 // Thread t's share of the partial rows of one group: items (row r, channel c_lo + j), j < n, in the order t, t + 128, ...
 // -- four at a time into four accumulators that are added pairwise at the end (four independent loads in flight: the
-// loop is latency-bound, 512 rows x 8 channels per block at 256x256), a fixed order shared by gn_from_partials_kernel and
+// loop is latency-bound, 512 rows x 8 channels per block at 256x256; t + k * GN_FOLD_NT in general), a fixed order shared by gn_from_partials_kernel and
 // gn_coeffs_from_partials_kernel so that both produce the same float64 sums.
+constexpr int GN_FOLD_NT = 256;      // threads of the two fold kernels (one block per (group, image))
 __device__ __forceinline__ void gn_fold_rows(const float* p, int C, int rows, int n, int c_lo, int img, int t, double& a, double& b) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     const int total = rows * n;
@@ -376,11 +377,11 @@ __device__ __forceinline__ void gn_fold_rows(const float* p, int C, int rows, in
             sb += (double)q[C];
         }
     };
-    for (int i = t; i < total; i += 512) {
+    for (int i = t; i < total; i += 4 * GN_FOLD_NT) {
         item(i, a0, b0);
-        item(i + 128, a1, b1);
-        item(i + 256, a2, b2);
-        item(i + 384, a3, b3);
+        item(i + GN_FOLD_NT, a1, b1);
+        item(i + 2 * GN_FOLD_NT, a2, b2);
+        item(i + 3 * GN_FOLD_NT, a3, b3);
     }
     a += (a0 + a1) + (a2 + a3);
     b += (b0 + b1) + (b2 + b3);
@@ -389,9 +390,9 @@ __device__ __forceinline__ void gn_fold_rows(const float* p, int C, int rows, in
 // partial rows [img][row][0|1][C] (sum | sum of squares per channel) of a (two-source) tensor -> per-(image, group) sums
 // in float64, written (not added) in a fixed order: one block per (group, image); thread t adds the (row, channel) items
 // t, t + 128, ... of the group in float64, the 128 thread sums are added by a fixed tree in LDS.
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(GN_FOLD_NT)
     gn_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, double* stats, int G) {
-    __shared__ double red[2][128];
+    __shared__ double red[2][GN_FOLD_NT];
     const int g = blockIdx.x, img = blockIdx.y;
     const int cpg = (C0 + C1) / G;
     const int t = threadIdx.x;
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(128)
     red[0][t] = a;
     red[1][t] = b;
     __syncthreads();
-    for (int w = 64; w > 0; w >>= 1) {
+    for (int w = GN_FOLD_NT / 2; w > 0; w >>= 1) {
         if (t < w) {
             red[0][t] += red[0][t + w];
             red[1][t] += red[1][t + w];
@@ -424,11 +425,11 @@ __global__ void __launch_bounds__(128)
 // (group, image) folds the partial rows exactly as gn_from_partials_kernel does -- same items per thread, same tree, so
 // the float64 sums are the same bits -- and its first C / G threads write the group's channels' coefficients with
 // gn_coeffs_kernel's arithmetic.
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(GN_FOLD_NT)
     gn_coeffs_from_partials_kernel(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1, const float* gamma,
                                    const float* beta, const float* scale, const float* shift, int ld_ss, float* coefA,
                                    float* coefB, int ld_coef, int HW, int G, float eps) {
-    __shared__ double red[2][128];
+    __shared__ double red[2][GN_FOLD_NT];
     const int g = blockIdx.x, img = blockIdx.y;
     const int C = C0 + C1;
     const int cpg = C / G;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(128)
     red[0][t] = a;
     red[1][t] = b;
     __syncthreads();
-    for (int w = 64; w > 0; w >>= 1) {
+    for (int w = GN_FOLD_NT / 2; w > 0; w >>= 1) {
         if (t < w) {
             red[0][t] += red[0][t + w];
             red[1][t] += red[1][t + w];
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(128)
     double var = red[1][0] * inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int c = c_lo + t; c < c_hi; c += 128) {
+    for (int c = c_lo + t; c < c_hi; c += GN_FOLD_NT) {
         double ca = rstd * (double)gamma[c];
         double cb = (double)beta[c] - mean * ca;
         if (scale) {
@@ -622,7 +623,7 @@ extern "C" int nd_groupnorm_stats_from_partials(const float* p0, int C0, int row
     ND_REQUIRE(p0 && stats && NI > 0 && C0 > 0 && rows0 > 0 && C1 >= 0 && G > 0 && G <= 128 && (C0 + C1) % G == 0, fn,
                "bad arguments");
     if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
-    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(G, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(G, NI), dim3(GN_FOLD_NT), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
                        rows0, C1 > 0 ? p1 : p0, C1, C1 > 0 ? rows1 : 0, stats, G);
     return check_launch(fn);
 }
@@ -636,7 +637,7 @@ extern "C" int nd_groupnorm_coeffs_from_partials(const float* p0, int C0, int ro
                (C0 + C1) % G == 0, fn, "bad arguments");
     if (C1 > 0) ND_REQUIRE(p1 != nullptr && rows1 > 0, fn, "second source");
     ND_REQUIRE((scale == nullptr) == (shift == nullptr) && ld_coef >= C0 + C1, fn, "scale/shift go together; ld_coef >= C");
-    hipLaunchKernelGGL(gn_coeffs_from_partials_kernel, dim3(G, NI), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
+    hipLaunchKernelGGL(gn_coeffs_from_partials_kernel, dim3(G, NI), dim3(GN_FOLD_NT), 0, reinterpret_cast<hipStream_t>(stream), p0, C0,
                        rows0, C1 > 0 ? p1 : p0, C1, C1 > 0 ? rows1 : 0, gamma, beta, scale, shift, ld_ss, coefA, coefB, ld_coef,
                        HW, G, eps);
     return check_launch(fn);
