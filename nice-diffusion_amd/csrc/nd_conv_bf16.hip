@@ -1139,274 +1139,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// ---- An experiment that measures EQUAL to the register-streamed form: compiled only with
-//      `make EXPERIMENTAL=1`; without it variants 12 / 13 stay reserved and a launch reports "not built".
-#if defined(ND_EXPERIMENTAL_KERNELS)
-// ------------------------------------------------------------------------------------------------------------
-// 3x3 form with BOTH operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write).
-// Ablations of the kernel above put the weight-fragment stream (global -> VGPR per wave, two waves fetching every
-// fragment, in-order vmcnt coupling it to the halo fetches) at 1.4x of the run time.  Here a block's weight fragments
-// cross L2 -> CU once: per tap the 8 waves DMA the tap's 4 k-steps x BN/32 fragments (32 KiB for BN = 256) into one of
-// two LDS stages while the previous stage is consumed; the next chunk's halo goes the same way, one 1 KiB piece per wave
-// and tap, with the XOR swizzle applied to the per-lane SOURCE address (the LDS side of a DMA is lane-linear).  One
-// "vmcnt(0) + barrier" per tap publishes everything issued during the tap; nothing is counted by hand.
-
-template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM* WN * 64, 2)
-    conv_bf16w_kernel(const ConvArgsH p, const __bf16* zero16) {
-    constexpr int NW = WM * WN;
-    constexpr int BN = WN * TN * 32;
-    constexpr int NTB = BN / 32;                       // n tiles per block
-    constexpr int STAGE_W = 4 * NTB * 256;             // 4-byte words per weight stage (one tap: 4 k-steps x NTB fragments)
-    constexpr int NFW = 4 * NTB / NW;                  // weight DMAs per wave and tap
-    static_assert(4 * NTB % NW == 0, "");
-    constexpr int ROWF = 32;                           // words per halo pixel row (64 bf16 channels)
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 halo buffers][2 weight stages]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave - wm * WN;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int mblk, nblk;
-    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-    const int NPIECE = (HP * 8 + 63) >> 6;             // 1 KiB pieces per halo buffer
-    const int HBUF_W = NPIECE * 256;                   // words per halo buffer
-    float* wring = smem + 2 * HBUF_W;
-
-    auto swz = [](int hp) -> int { return (hp >> 1) & 7; };
-
-    // ---- halo DMA descriptors: piece u = k * NW + wave (k = tap that issues it); lane -> 16-byte unit U = u*64 + lane =
-    //      physical slot U & 7 of halo pixel U >> 3, which holds logical channel slot (U & 7) ^ swz(pixel)
-    const int Ctot = p.C0 + p.C1;
-    int gpx[9];
-    int hsl[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int U = (k * NW + wave) * 64 + lane;
-        const int hp = U >> 3;
-        int g = -1;
-        if (hp < HP) {
-            const int li = hp / HPI;
-            const int rem = hp - li * HPI;
-            const int hy = rem / HW;
-            const int hx = rem - hy * HW;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-        }
-        gpx[k] = g;
-        hsl[k] = ((U & 7) ^ swz(hp)) << 3;
-    }
-    // Exactly ONE halo DMA per wave and call, so that the in-flight count per tap is uniform: pieces past the buffer
-    // (wave-uniform) become a 16-byte-per-lane copy of zeros into a per-wave scratch piece behind the weight ring.
-    float* scratch = wring + 2 * STAGE_W + wave * 256;
-    auto issue_halo = [&](int k, int ch, int buf, bool real) {
-        const int u = k * NW + wave;
-        const bool live = real && u < NPIECE;
-        const int c = ch * 64 + hsl[k];
-        const int g = gpx[k];
-        const __bf16* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
-                                       : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
-        src = (live && g >= 0 && c < Ctot) ? src : zero16;
-        ND_GLDS16H(src, live ? (smem + buf * HBUF_W + u * 256) : scratch);
-    };
-
-    // ---- weight DMAs: fragment f = j * NW + wave of a tap stage = (k-step f / NTB, n tile f % NTB)
-    const __bf16* wsrc[NFW];
-    int wdst[NFW];
-#pragma unroll
-    for (int j = 0; j < NFW; ++j) {
-        const int f = j * NW + wave;
-        const int ks = f / NTB, nl = f - ks * NTB;
-        int ntile = nblk * NTB + nl;
-        if (ntile > p.NT32 - 1) ntile = p.NT32 - 1;
-        wsrc[j] = p.w + ((size_t)ntile * 36 + ks) * 512 + lane * 8;
-        wdst[j] = (ks * NTB + nl) * 256;
-    }
-    const size_t c64_stride = (size_t)p.NT32 * 36 * 512;
-    auto issue_w = [&](int ch, int tap, int stage) {
-#pragma unroll
-        for (int j = 0; j < NFW; ++j)
-            ND_GLDS16H(wsrc[j] + (size_t)ch * c64_stride + tap * (4 * 512), wring + stage * STAGE_W + wdst[j]);
-    };
-
-    int a_hp[TM];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = (wm * TM + mi) * 32 + l31;
-        const int li = m >> (p.thl + p.twl);
-        const int py = (m >> p.twl) & (TH - 1);
-        const int px = m & (TW - 1);
-        a_hp[mi] = li * HPI + py * HW + px;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-    const int nchunks = p.NC64;
-    // ---- prologue: chunk 0 halo (all pieces), tap 0 weights
-#pragma unroll
-    for (int k = 0; k < 9; ++k) issue_halo(k, 0, 0, true);
-    issue_w(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    int gt = 0;                                         // global tap counter: weight stage = gt & 1
-    f32x4 a_fr[TM], b_fr[2][TN];
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * HBUF_W;
-#pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx, ++gt) {
-                const int tap = dy * 3 + dx;
-                const float* wst = wring + (gt & 1) * STAGE_W + ((wn * TN) * 64 + lane) * 4;
-                // fill the other stage with the next tap (past the last chunk: the packed tensor's zero chunk) and send
-                // this tap's piece of the next chunk's halo on its way
-                {
-                    const int ntap = (tap == 8) ? 0 : tap + 1;
-                    issue_w(ch + (tap == 8 ? 1 : 0), ntap, (gt + 1) & 1);
-                    issue_halo(tap, ch + 1, (ch + 1) & 1, ch + 1 < nchunks);       // the YOUNGEST operation of the tap
-                }
-                const int tapoff = dy * HW + dx;
-                // this tap's first fragments
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) b_fr[0][ni] = *reinterpret_cast<const f32x4*>(wst + ni * 256);
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int hp = a_hp[mi] + tapoff;
-                    a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((lh ^ swz(hp)) << 2));
-                }
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    const int cur = kc & 1, nxt = cur ^ 1;
-                    if (kc < 3) {
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            b_fr[nxt][ni] = *reinterpret_cast<const f32x4*>(wst + ((kc + 1) * NTB + ni) * 256);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    ND_PRIO(1);
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b_fr[cur][ni]), as_bf16x8(a_fr[mi]),
-                                                                                  acc[mi][ni], 0, 0, 0);
-                        if (kc < 3) {
-                            const int hp = a_hp[mi] + tapoff;
-                            const int nslot = ((kc + 1) << 1) | lh;
-                            a_fr[mi] = *reinterpret_cast<const f32x4*>(hbuf + hp * ROWF + ((nslot ^ swz(hp)) << 2));
-                        }
-                    }
-                    if (kc < 3) {
-#pragma unroll
-                        for (int mi = 0; mi < TM; ++mi) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    }
-                    ND_PRIO(0);
-                }
-                // publish: the weight DMAs this wave issued during the tap have landed (vmcnt(1): all but the youngest
-                // operation, this tap's halo piece, which is older than everything the NEXT tap's wait leaves in flight --
-                // so a halo piece has two taps to arrive and only the chunk's last tap, below, waits for all of them);
-                // every LDS read of the tap is done
-                if (tap == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-    }
-
-    // ---- epilogue (as conv_bf16_kernel): lane = one pixel, register group g4 = 4 consecutive output channels
-    const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0);
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = (wm * TM + mi) * 32 + l31;
-        const int li = m >> (p.thl + p.twl);
-        const int oy = oy0 + ((m >> p.twl) & (TH - 1));
-        const int ox = ox0 + (m & (TW - 1));
-        const int img = img0 + li;
-        if (img < p.NI && oy < p.H && ox < p.W) {
-            const size_t opix = (size_t)(img * p.H + oy) * p.W + ox;
-            const float* rb = p.rowbias ? p.rowbias + (size_t)img * p.ld_rowbias : nullptr;
-            const __bf16* rr = nullptr;
-            if (p.res) {
-                const size_t rp = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) : opix;
-                rr = p.res + rp * p.ldr;
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
-                    if (n + 3 < p.N && vec_ok) {
-                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2],
-                                   acc[mi][ni][4 * g4 + 3]};
-                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                        if (rb) v += *reinterpret_cast<const f32x4*>(rb + n);
-                        if (rr) {
-                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                        }
-                        if (p.silu_out) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
-                        }
-                        if (p.out_f32) {
-                            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + opix * p.ldo + n) = v;
-                        } else {
-                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + opix * p.ldo + n) = o;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (n + e < p.N) {
-                                float v = acc[mi][ni][4 * g4 + e];
-                                if (p.bias) v += p.bias[n + e];
-                                if (rb) v += rb[n + e];
-                                if (rr) v += (float)rr[n + e];
-                                if (p.silu_out) v = fast_silu(v);
-                                if (p.out_f32) static_cast<float*>(p.out)[opix * p.ldo + n + e] = v;
-                                else static_cast<__bf16*>(p.out)[opix * p.ldo + n + e] = (__bf16)v;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-#endif  // ND_EXPERIMENTAL_KERNELS
+// (Variants 12 / 13 -- conv_bf16w_kernel, both operands through LDS by LDS-DMA -- gave the same bits and measured EQUAL to
+//  the register-streamed form; variant 22 -- gemm_bf16x_kernel, 128 px x 128 ch per wave, one block per CU -- measured
+//  0.72-0.93 of gemm_bf16q_kernel.  Their code was removed in round 4 (git history); the numbers stay retired.)
 
 // ------------------------------------------------------------------------------------------------------------
 // GEMM-shaped 1x1 form (flat pixel list): out[M][N] = x[M][K] . w[N][K]^T with K of a few hundred.  In the conv-shaped
@@ -1697,7 +1432,7 @@ static const VariantH kVariantsH[] = {
     {1, 4, 8, 1, 0, 0},   // 9: 256 x 128, 4 waves
     {1, 8, 4, 1, 0, 0},   // 10: 128 x 256, 8 waves
     {1, 4, 4, 2, 0, 0},   // 11: 128 x 256, 4 waves, wave tile 128 px x 64 ch
-    // both operands through LDS (LDS-DMA), 3x3 only
+    // RETIRED (conv_bf16w_kernel: both operands through LDS by LDS-DMA, measured equal; removed in round 4)
     {2, 4, 4, 2, 1, 0},   // 12: 256 x 256, 8 waves
     {2, 4, 2, 2, 1, 0},   // 13: 128 x 256, 8 waves
     // v_mfma_f32_16x16x32_bf16 forms (tm, tn in 16-wide tiles)
@@ -1712,7 +1447,7 @@ static const VariantH kVariantsH[] = {
     // GEMM-shaped 1x1, two blocks per CU (nd_gemm_bf16_quad.hip): pixel rows through 4 LDS stages by LDS-DMA, weights
     // global -> VGPR; coded as ldsw = 3
     {1, 4, 4, 2, 3, 0},   // 21: 128 x 256, 4 waves
-    // the same with 128 px x 128 ch per wave: ONE block of four 512-register waves per CU (nd_gemm_bf16_wide.hip); ldsw = 4
+    // RETIRED (gemm_bf16x_kernel: 128 px x 128 ch per wave, one block per CU, measured slower; removed in round 4); ldsw = 4
     {2, 2, 4, 4, 4, 0},   // 22: 256 x 256, 4 waves
     // narrow outputs (the UNet's last convolution, 256 -> 6 channels): one 32-channel n tile per block instead of 64
     {4, 1, 1, 1, 0, 0},   // 23: 128 x  32, 4 waves, wave tile 32 px x 32 ch
@@ -1780,7 +1515,7 @@ static int select_variant_h(int variant, int taps, int pNI, int pH, int pW, int 
     for (int v = 0; v < kNumVariantsH; ++v) {
         if (variant >= 0 && v != variant) continue;
         const VariantH& V = kVariantsH[v];
-        if (V.ldsw == 1 && (taps != 9 || variant < 0)) continue;      // explicit choice only (the plan builder measures it)
+        if (V.ldsw == 1 || V.ldsw == 4) continue;                 // retired variants (kernels removed)
         if (V.ldsw >= 2 && (taps != 1 || variant < 0 || pNI != 1 || pH != 1)) continue;      // flat 1x1 only, explicit choice only
         if (V.mf && variant < 0) continue;                        // needs the layout-1 weights: explicit choice only
         if (V.mf && V.tm * V.tn >= 32) continue;                  // 128 px x 64 ch wave tile on 16x16 MFMAs: 154 registers spill (10x slower); kept only as an index
@@ -1815,16 +1550,6 @@ static int launch_h(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
     return check_launch("nd_conv_bf16_nhwc");
 }
 
-#if defined(ND_EXPERIMENTAL_KERNELS)
-template <int WM, int WN, int TM, int TN>
-static int launch_w(const ConvArgsH& a, const __bf16* zero16, int grid, size_t lds, hipStream_t s) {
-    auto kern = conv_bf16w_kernel<WM, WN, TM, TN>;
-    static bool attr_set[kMaxDevices] = {};
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_bf16_nhwc")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a, zero16);
-    return check_launch("nd_conv_bf16_nhwc");
-}
-#endif  // ND_EXPERIMENTAL_KERNELS
 
 template <int WM, int WN, int TM, int TN, int TAPS>
 static int launch_s(const ConvArgsH& a, int grid, size_t lds, hipStream_t s) {
@@ -1951,7 +1676,7 @@ extern "C" int64_t nd_conv_bf16_max_weight_read(int variant, int N, int C, int k
 extern "C" const char* nd_conv_bf16_variant_name(int variant) {
     if (variant < 0 || variant >= kNumVariantsH) return "";
     const VariantH& v = kVariantsH[variant];
-    return v.ldsw == 4 ? "nd::gemm_bf16x_kernel" : v.ldsw == 3 ? "nd::gemm_bf16q_kernel" : v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
+    return v.ldsw == 4 ? "(retired) nd::gemm_bf16x_kernel" : v.ldsw == 3 ? "nd::gemm_bf16q_kernel" : v.ldsw == 2 ? "nd::gemm_bf16_kernel" : v.ldsw == 1 ? "(retired) nd::conv_bf16w_kernel" : v.mf ? "nd::conv_bf16s_kernel"
                                                                                                : "nd::conv_bf16_kernel";
 }
 
@@ -2101,9 +1826,7 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
     }
     const int grid = a.mt * a.nt;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#if !defined(ND_EXPERIMENTAL_KERNELS)
-    if (V.ldsw == 4) return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
-#endif
+    if (V.ldsw == 4 || V.ldsw == 1) return fail_arg(fn, "retired variant (its kernel was removed; see the git history)");
     if (V.ldsw >= 3) {
         ND_REQUIRE(gnA == nullptr && rowbias == nullptr && !a.out_f32 && !a.silu_out && a.ksplit <= 1 && !a.up && !a.res_up, fn,
                    "the two-block GEMM form takes plain 1x1 convolutions with bf16 output only");
@@ -2113,13 +1836,6 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
                    "the two-block GEMM form needs 16-byte aligned output rows");
         ND_REQUIRE((double)M * ldx0 * 2 < 2147483648.0 && (double)M * (C1 ? ldx1 : 0) * 2 < 2147483648.0, fn,
                    "the two-block GEMM form addresses its inputs with 32-bit buffer offsets (< 2 GiB)");
-        if (V.ldsw == 4) {
-#if defined(ND_EXPERIMENTAL_KERNELS)
-            return launch_gemm_bf16x(a, grid, s);
-#else
-            return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
-#endif
-        }
         return launch_gemm_bf16q(a, grid, s);
     }
     if (V.ldsw == 2) {
@@ -2130,21 +1846,6 @@ static int conv_bf16_impl(const char* fn, const void* x0, int C0, int ldx0, cons
         if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, fn)) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)3 * 48 * 1024, s, a, zero16);
         return check_launch(fn);
-    }
-    if (V.ldsw) {
-        // 16 bytes of zeros for padded halo units: the tail of the packed weights' trailing zero chunk
-        const __bf16* zero16 = a.w + nd_conv_bf16_weight_elems(N, C0 + C1, ksize) - 8;
-        const size_t ldsw = lds_bytes_w(V, tp.hp);
-#if defined(ND_EXPERIMENTAL_KERNELS)
-        switch (v) {
-            case 12: return launch_w<2, 4, 4, 2>(a, zero16, grid, ldsw, s);
-            case 13: return launch_w<2, 4, 2, 2>(a, zero16, grid, ldsw, s);
-        }
-        return fail_arg(fn, "bad variant");
-#else
-        (void)zero16; (void)ldsw;
-        return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
-#endif
     }
     size_t lds = lds_bytes_h(taps, tp.hp) + lds_gn;
     a.coal = 0;

@@ -55,7 +55,5 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
 struct VariantH;
 // gemm_bf16q_kernel (nd_gemm_bf16_quad.hip), launched by nd_conv_bf16_nhwc's variant 21
 int launch_gemm_bf16q(const ConvArgsH& a, int grid, hipStream_t s);
-// gemm_bf16x_kernel (nd_gemm_bf16_wide.hip), variant 22: the same GEMM with 128 px x 128 ch per wave, one block per CU
-int launch_gemm_bf16x(const ConvArgsH& a, int grid, hipStream_t s);
 
 }  // namespace nd

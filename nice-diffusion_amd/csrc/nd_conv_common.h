@@ -143,8 +143,6 @@ __device__ __forceinline__ void sum8_over_32_lanes(f32x4& a, f32x4& b) {
 #undef ND_DPP8
 
 struct ConvArgs;
-// conv_winow_kernel (nd_conv_winograd_wave.hip), launched by nd_conv3x3_winograd_nhwc's variant 11 (experimental build only)
-int launch_winow(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
 // conv_wino4_kernel (nd_conv_winograd_quad.hip), launched by nd_conv3x3_winograd_nhwc's variant 12: 4 waves, 128 px x 64 ch,
 // two blocks per CU; its halo buffers are filled by kWino4HaloRounds LDS-DMA rounds of 4 waves x 64 lanes x 16 bytes
 constexpr int kWino4HaloRounds = 7;

@@ -729,647 +729,9 @@ __global__ void __launch_bounds__(1024, 4)
     }
 }
 
-// ---- Experiments that were built, are bit-identical to conv_wino16_kernel, and measure SLOWER: the
-//      persistent form (variant 10) and the LDS-DMA operand streams (variant 9).  They are compiled only with
-//      `make EXPERIMENTAL=1` (-DND_EXPERIMENTAL_KERNELS); without it their variant numbers stay reserved and a launch
-//      reports "not built".  tests/ exercise them when they are built.
-#if defined(ND_EXPERIMENTAL_KERNELS)
-// ------------------------------------------------------------------------------------------------------------
-// Persistent form of conv_wino16_kernel: one block per CU walks several tiles.  A 16-wave block owns its CU (154 KB of
-// LDS), so in the one-tile-per-block form nothing overlaps a tile's prologue (first halo chunk + first weight
-// fragments: ~2 us of HBM / L2 latency) -- 4 % of a 384-channel tile, 8 % of a 192-channel one.  Here the next tile's
-// chunk 0 is fetched during the current tile's last chunk into halo buffer 0 (the last chunk has an odd index and lives
-// in buffer 1: the host requires an even number of chunks) and the epilogue's exchange buffers sit behind buffer 0.
-// Same MFMA order and association as conv_wino16_kernel: identical bits.
-__global__ void __launch_bounds__(1024, 4)
-    conv_wino16p_kernel(const ConvArgs p) {
-    constexpr int NSUB = 1;
-    constexpr int NT = 1024, WNT = 3, BN = 96;
-    constexpr int ROWF = 32 * NSUB, SPR = 8 * NSUB;
-    constexpr int FRAGS = 64;
-    constexpr int HPMAX = 208;
-    constexpr int MAXHI = (HPMAX * SPR + NT - 1) / NT;      // 2 (NSUB 1) or 4 (NSUB 2)
-    constexpr int HB = (MAXHI + 1) / 2;
-    constexpr int NSTEP = 4 * NSUB;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // = transform position 4*xi + nu
-    const int xi = wave >> 2;
-    const int nu = wave & 3;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    // ---- persistent over tiles: block b takes tiles b, b + gridDim.x, ... (same XCD-aware order as the one-tile-per-block
-    //      form, with the tile count in place of the grid size); the NEXT tile's first halo chunk and first weight fragments
-    //      are fetched during the current tile's last chunk, so only the block's very first tile pays the prologue latency
-    // Only the tile id is carried around the tile loop; a tile's coordinates are re-derived from it where they are needed
-    // (tile start, last k-step, epilogue): the one-tile form already uses 94 of the 102 scalar registers.
-    const int total = p.mt * p.nt;
-    struct Tile { int tx, ty, img0, oy0, ox0, n0, nblk; };
-    auto decode = [&](int t) -> Tile {
-        const int q = total >> 3, r = total & 7;
-        const int xcd = t & 7;
-        const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-        int mblk, nblk;
-        tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-        Tile d;
-        d.tx = mblk % p.tiles_x;
-        const int tmp = mblk / p.tiles_x;
-        d.ty = tmp % p.tiles_y;
-        const int ig = tmp / p.tiles_y;
-        d.img0 = ig << p.nibl; d.oy0 = d.ty << p.thl; d.ox0 = d.tx << p.twl;
-        d.n0 = nblk * BN; d.nblk = nblk;
-        return d;
-    };
-    int tcur = blockIdx.x;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-
-    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel
-        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
-        if (SPR == 8) return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
-        return hp * ROWF + ((slot ^ key) << 2);
-    };
-    const int hslot = tid % SPR;
-    const int hrow0 = tid / SPR;
-    int gpix[MAXHI], gnext[MAXHI], hoff[MAXHI];      // hoff does not depend on the tile
-    auto halo_desc = [&](const Tile& d, bool valid, int (&gp)[MAXHI], bool with_off) {
-#pragma unroll
-        for (int k = 0; k < MAXHI; ++k) {
-            const int hp = hrow0 + k * (NT / SPR);
-            int g = -1, ho = -1;
-            if (hp < HP) {
-                const int li = hp / HPI;
-                const int rem = hp - li * HPI;
-                const int hy = rem / HW;
-                const int hx = rem - hy * HW;
-                const int img = d.img0 + li;
-                const int iy = d.oy0 - 1 + hy, ix = d.ox0 - 1 + hx;
-                if (valid && img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-                ho = lds_off(hp, hy, hx, hslot);
-            }
-            gp[k] = g;
-            if (with_off) hoff[k] = ho;
-        }
-    };
-    halo_desc(decode(tcur), true, gpix, true);
-    const int Ctot = p.C0 + p.C1;
-    const int nchunks = (p.NC32 + NSUB - 1) / NSUB;
-
-    // (this form does not fold GroupNorm into the loader: the host refuses gnA for it)
-    auto load_halo_pixel = [&](int g, int ch) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int c = ch * ROWF + (hslot << 2);
-        if (g >= 0 && c < Ctot) {
-            const float* src = (c < p.C0) ? (p.x0 + (size_t)g * p.ldx0 + c) : (p.x1 + (size_t)g * p.ldx1 + (c - p.C0));
-            v = *reinterpret_cast<const f32x4*>(src);
-        }
-        return v;
-    };
-    auto store_halo_item = [&](int k, int buf, f32x4 v) {
-        if (hoff[k] >= 0) *reinterpret_cast<f32x4*>(smem + buf * (HP * ROWF) + hoff[k]) = v;
-    };
-
-    // V[xi][nu] = sum_{a,b} Bt[xi][a] d[a][b] Bt[nu][b]; every row of Bt has two non-zeros (+-1):
-    //   index 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
-    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
-    const float sgr = (xi == 1) ? 1.f : -1.f;
-    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
-    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
-    const float sgc = (nu == 1) ? 1.f : -1.f;
-
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    int off4[4];          // LDS float offsets (k-step 0) of d[ra][ca], d[rb][ca], d[ra][cb], d[rb][cb] of this lane's tile
-    {
-        const int t = l31;
-        const int t_li = t >> (thl2 + twl2);
-        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-        const int t_x = t & ((1 << twl2) - 1);
-        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
-        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
-        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
-        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
-    }
-
-    // weight fragments of this position for the three n tiles (N tail: clamped, results dropped in the epilogue)
-    const float* bp;
-    int noff[WNT];
-    auto set_weights = [&](int nblk_) {
-        const int ntile0 = nblk_ * WNT;
-        bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
-#pragma unroll
-        for (int rr = 0; rr < WNT; ++rr) {
-            int nt_ = ntile0 + rr;
-            if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
-            noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
-        }
-    };
-    set_weights(decode(tcur).nblk);
-    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
-
-    f32x16 acc[WNT];
-
-    f32x4 bfr[2][WNT];
-    auto load_b = [&](f32x4 (&dst)[WNT], int c32, int kc) {
-        const float* qq = bp + (size_t)c32 * c32_stride + kc * (16 * 256);
-#if !defined(ND_WABL_NOB)
-#pragma unroll
-        for (int rr = 0; rr < WNT; ++rr) dst[rr] = *reinterpret_cast<const f32x4*>(qq + noff[rr]);
-#else
-        asm volatile("" :: "v"(qq));
-#endif
-    };
-
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k)
-        if (k < p.nhi) store_halo_item(k, 0, load_halo_pixel(gpix[k], 0));
-    load_b(bfr[0], 0, 0);
-    __syncthreads();
-
-  for (;;) {
-    const int tnext = tcur + (int)gridDim.x;
-    const bool has_next = tnext < total;
-    // the next tile's halo descriptors are worked out here, where few registers are live, not inside the chunk loop
-    halo_desc(decode(has_next ? tnext : tcur), has_next, gnext, false);
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * (HP * ROWF);
-        const bool more = (ch + 1) < nchunks;
-        // the last chunk (odd index: it lives in buffer 1) fetches the NEXT tile's chunk 0 into buffer 0
-        const bool halo_next = more || has_next;
-        const int nch = more ? ch + 1 : 0;                 // chunk to fetch
-        const int nbuf = more ? ((ch + 1) & 1) : 0;        // buffer to park it in
-        int nvalid = (p.NC32 - ch * NSUB) * 4;
-        if (nvalid > NSTEP) nvalid = NSTEP;
-        f32x4 phb[HB];
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st < nvalid) {
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < NSTEP) load_b(bfr[nxt], ch * NSUB + ((st + 1) >> 2), (st + 1) & 3);
-                else if (more) load_b(bfr[nxt], (ch + 1) * NSUB, 0);
-                else {                                   // first fragments of the next tile (its n block may differ)
-                    if (has_next) set_weights(decode(tnext).nblk);
-                    load_b(bfr[nxt], 0, 0);
-                }
-                if (st == 0 || st == NSTEP / 2) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st ? HB : 0) + i;
-#if !defined(ND_WABL_NOHALO)
-                        if (k < MAXHI && k < p.nhi) phb[i] = load_halo_pixel(halo_next ? (more ? gpix[k] : gnext[k]) : -1, nch);
-#else
-                        if (k < MAXHI && k < p.nhi) phb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-                    }
-                }
-                // (no sched_barrier here: letting the compiler interleave the loads with the previous MFMAs measures 1-2 % faster)
-                f32x4 v;
-                {
-                    int kx = st << 3;
-                    asm volatile("" : "+s"(kx));
-#if !defined(ND_WABL_NOA)
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
-                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
-                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
-#else
-                    const f32x4 d0 = f32x4{(float)(off4[0] ^ kx), 1.f, 2.f, 3.f}, d1 = f32x4{(float)(off4[1] ^ kx), 1.f, 2.f, 3.f};
-                    const f32x4 d2 = f32x4{(float)(off4[2] ^ kx), 1.f, 2.f, 3.f}, d3 = f32x4{(float)(off4[3] ^ kx), 1.f, 2.f, 3.f};
-#endif
-                    const f32x4 ta = d0 + sgr * d1;          // tr[ca]
-                    const f32x4 tb = d2 + sgr * d3;          // tr[cb]
-                    v = ta + sgc * tb;
-                }
-                __builtin_amdgcn_s_setprio(2);          // a wave with its operands ready issues ahead of waves still loading: +1 %
-#pragma unroll
-                for (int rr = 0; rr < WNT; ++rr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][rr][j], v[j], acc[rr], 0, 0, 0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                if ((st == 1 || st == NSTEP / 2 + 1) && halo_next) {
-#pragma unroll
-                    for (int i = 0; i < HB; ++i) {
-                        const int k = (st == 1 ? 0 : HB) + i;
-                        if (k < MAXHI && k < p.nhi) store_halo_item(k, nbuf, phb[i]);
-                    }
-                }
-            }
-        }
-#if !defined(ND_WABL_NOBARRIER)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#endif
-    }
-
-#if defined(ND_WABL_NOEPI)
-    if (acc[0][0] == 123.456f && acc[1][3] == 1.5f && acc[2][7] == 2.5f) p.out[0] = 1.f;
-    return;
-#endif
-    // ---- epilogue: three rounds (one per n tile) through two exchange buffers ex[buf][pos][group][lane][4].
-    //      Accumulators are M^T (row = channel, col = tile): register group g4 of a lane = 4 consecutive channels of its
-    //      tile.  Reader wave w finishes output pixel (a, b) = (w >> 3, (w >> 2) & 1) of channel group g4 = w & 3:
-    //      Y[a][b] = sum_xi At[a][xi] (sum_nu At[b][nu] M[xi][nu]),  At = [[1,1,1,0],[0,1,-1,-1]].
-    const Tile T = decode(tcur);
-    const int img0 = T.img0, oy0 = T.oy0, ox0 = T.ox0, n0 = T.n0, tx = T.tx, ty = T.ty;
-    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
-    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
-    const int te = l31;
-    const int li = te >> (thl2 + twl2);
-    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-    const int txx = te & ((1 << twl2) - 1);
-    const int img = img0 + li;
-    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
-    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
-    // residual rows of the three rounds are fetched now, so that their HBM latency hides behind the LDS exchange
-    f32x4 resv[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
-        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
-            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                        : ((size_t)(img * p.H + oy) * p.W + ox);
-            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
-        }
-    }
-    __syncthreads();            // last chunk's halo fully consumed
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        {
-            // round rr+2 reuses this buffer: every wave has passed the barrier of round rr+1 by then, i.e. finished
-            // reading round rr
-            float* exw = smem + HP * ROWF + (rr & 1) * (16 * 4 * 256);      // behind buffer 0, which holds the next tile's chunk 0
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
-            }
-        }
-        __syncthreads();
-        {
-            const float* exr = smem + HP * ROWF + (rr & 1) * (16 * 4 * 256);
-            f32x4 rx[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int x2 = pa + i;
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
-                rx[i] = (m0 + sb * m1) + sb * m2;
-            }
-            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
-            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
-            f32x4 fin = {0.f, 0.f, 0.f, 0.f};          // what was stored (zeros for lanes / channels that store nothing)
-            if (pix_ok && nb < p.N) {
-                const bool vec = p.vec_ok && (nb + 3 < p.N);
-                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
-                const float* rp = nullptr;
-                if (p.res) {
-                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                : ((size_t)(img * p.H + oy) * p.W + ox);
-                    rp = p.res + rpx * p.ldr + nb;
-                }
-                if (vec) {
-                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
-                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    yv += resv[rr];           // zeros without a residual
-                    if (p.silu_out) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = yv;
-                    fin = yv;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (nb + c < p.N) {
-                            float v2 = yv[c];
-                            if (p.bias) v2 += p.bias[nb + c];
-                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
-                            if (rp) v2 += rp[c];
-                            if (p.silu_out) v2 = fast_silu(v2);
-                            op[c] = v2;
-                            fin[c] = v2;
-                        }
-                    }
-                }
-            }
-            if (p.chstats) {
-                // GroupNorm statistics of the output for free: per-channel sum / sum of squares over this wave's pixels of
-                // each image (the tiles of one image are a power-of-two run of lanes), stored as one partial row per
-                // (image, m block, pixel-wave): no atomics, and the consumer reads N floats x 8 x m-blocks per image
-                // instead of the whole tensor.
-                f32x4 sq = fin * fin;
-                const int gl = 1 << (thl2 + twl2);          // tiles (= lanes of a half-wave) per image
-                for (int m = 1; m < gl; m <<= 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        fin[c] += __shfl_xor(fin[c], m);
-                        sq[c] += __shfl_xor(sq[c], m);
-                    }
-                }
-                if ((l31 & (gl - 1)) == 0 && img < p.NI && nb < p.N) {
-                    const int mb = (p.nibl == 0) ? (ty * p.tiles_x + tx) : 0;
-                    float* ps = p.chstats + ((((size_t)img * p.mbi + mb) * 4 + (wave >> 2)) * 2) * p.N + nb;
-                    if (nb + 3 < p.N && (p.N & 3) == 0) {
-                        *reinterpret_cast<f32x4*>(ps) = fin;
-                        *reinterpret_cast<f32x4*>(ps + p.N) = sq;
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (nb + c < p.N) {
-                                ps[c] = fin[c];
-                                ps[p.N + c] = sq[c];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (!has_next) break;
-    __syncthreads();            // every wave has finished reading the exchange buffers, which overlap halo buffer 1
-    tcur = tnext;
-#pragma unroll
-    for (int k = 0; k < MAXHI; ++k) gpix[k] = gnext[k];
-  }
-}
-
-#define ND_GLDS16(gptr, lptr)                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-__global__ void __launch_bounds__(1024, 4)
-    conv_wino16g_kernel(const ConvArgs p) {
-    constexpr int WNT = 3, BN = 96;
-    constexpr int ROWF = 32;
-    constexpr int FRAGS = 64;
-    constexpr int HUNITS = 2048;                 // 16-byte units per halo buffer = 2 DMAs x 16 waves x 64 lanes
-    constexpr int HBUF = HUNITS * 4;             // floats
-    constexpr int RING0 = 2 * HBUF;              // float offset of the weight ring
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;          // = transform position 4*xi + nu
-    const int xi = wave >> 2;
-    const int nu = wave & 3;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
-    const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int mblk, nblk;
-    tile_of(idp, p.mt, p.nt, p.ngroup, mblk, nblk);
-    const int tx = mblk % p.tiles_x;
-    const int tmp = mblk / p.tiles_x;
-    const int ty = tmp % p.tiles_y;
-    const int ig = tmp / p.tiles_y;
-
-    const int TH = 1 << p.thl, TW = 1 << p.twl;
-    const int HH = TH + 2, HW = TW + 2;
-    const int HPI = HH * HW;
-    const int HP = HPI << p.nibl;
-    const int img0 = ig << p.nibl, oy0 = ty << p.thl, ox0 = tx << p.twl;
-    const int n0 = nblk * BN;
-
-    auto lds_off = [&](int hp, int hy, int hx, int slot) -> int {      // same image as conv_wino_kernel (SPR = 8)
-        const int key = (((hy >> 1) & 3) << 2) | ((hx >> 1) & 3);
-        return (hp >> 1) * 64 + (((((hp & 1) << 3) | slot) ^ key) << 2);
-    };
-
-    // ---- halo DMA descriptors.  DMA k of this wave fills units (k*16 + wave)*64 + lane of the buffer; unit U is slot
-    //      s' = U & 15 of the 256-byte row of pixel pair U >> 4; un-swizzling gives the pixel and channel slot it holds.
-    const int Ctot = p.C0 + p.C1;
-    int gpx[2], hsl[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int U = (k * 16 + wave) * 64 + lane;
-        const int pp = U >> 4;
-        const int hp0 = pp * 2;
-        int g = -1, sl = 0;
-        if (hp0 < HP) {
-            const int li = hp0 / HPI;
-            const int rem = hp0 - li * HPI;
-            const int hy = rem / HW;
-            const int hx0 = rem - hy * HW;              // even; the pair (hx0, hx0 + 1) shares the swizzle key
-            const int key = (((hy >> 1) & 3) << 2) | ((hx0 >> 1) & 3);
-            const int t = (U & 15) ^ key;
-            const int hx = hx0 + (t >> 3);
-            sl = t & 7;
-            const int img = img0 + li;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            if (img < p.NI && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                g = (img * p.Hs + (iy >> p.up)) * p.Ws + (ix >> p.up);
-        }
-        gpx[k] = g;
-        hsl[k] = sl << 2;
-    }
-    const float* zero16 = p.zero;
-    auto halo_src = [&](int k, int ch) -> const float* {
-        const int c = ch * ROWF + hsl[k];
-        const int g = gpx[k];
-        const float* src = (c < p.C0) ? (p.x0 + (size_t)(g < 0 ? 0 : g) * p.ldx0 + c)
-                                      : (p.x1 + (size_t)(g < 0 ? 0 : g) * p.ldx1 + (c - p.C0));
-        return (g >= 0 && c < Ctot) ? src : zero16;
-    };
-    auto issue_halo = [&](int ch, int buf) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) ND_GLDS16(halo_src(k, ch), smem + buf * HBUF + (k * 16 + wave) * 256);
-    };
-
-    const int ra = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
-    const int rb = (xi == 0) ? 2 : ((xi == 1) ? 2 : ((xi == 2) ? 1 : 3));
-    const float sgr = (xi == 1) ? 1.f : -1.f;
-    const int ca = (nu == 0) ? 0 : ((nu == 2) ? 2 : 1);
-    const int cb = (nu == 0) ? 2 : ((nu == 1) ? 2 : ((nu == 2) ? 1 : 3));
-    const float sgc = (nu == 1) ? 1.f : -1.f;
-
-    const int twl2 = p.twl - 1, thl2 = p.thl - 1;
-    int off4[4];
-    {
-        const int t = l31;
-        const int t_li = t >> (thl2 + twl2);
-        const int t_y = (t >> twl2) & ((1 << thl2) - 1);
-        const int t_x = t & ((1 << twl2) - 1);
-        const int base = t_li * HPI + (2 * t_y) * HW + 2 * t_x;
-        off4[0] = lds_off(base + ra * HW + ca, 2 * t_y + ra, 2 * t_x + ca, lh);
-        off4[1] = lds_off(base + rb * HW + ca, 2 * t_y + rb, 2 * t_x + ca, lh);
-        off4[2] = lds_off(base + ra * HW + cb, 2 * t_y + ra, 2 * t_x + cb, lh);
-        off4[3] = lds_off(base + rb * HW + cb, 2 * t_y + rb, 2 * t_x + cb, lh);
-    }
-
-    const int ntile0 = nblk * WNT;
-    const float* bp = p.w + ((size_t)ntile0 * FRAGS + wave) * 256 + lane * 4;
-    int noff[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        int nt_ = ntile0 + rr;
-        if (nt_ > p.NT32 - 1) nt_ = p.NT32 - 1;
-        noff[rr] = (nt_ - ntile0) * (FRAGS * 256);
-    }
-    const size_t c32_stride = (size_t)p.NT32 * (FRAGS * 256);
-    float* ring = smem + RING0 + wave * (2 * WNT * 256);      // this wave's 2 slots x 3 fragments
-    // fragments of global k-step gs = 4*c32 + kc go to ring slot gs & 1
-    static_assert(wstream::pad_chunks(wstream::kWinoDmaAhead, wstream::kWinoStepsPerChunk) <= wstream::kWinoPadChunks,
-                  "weight read-ahead exceeds the packer's zero padding");
-    auto issue_b = [&](int gs) {
-        const float* qq = bp + (size_t)(gs >> 2) * c32_stride + (gs & 3) * (16 * 256);
-#pragma unroll
-        for (int rr = 0; rr < WNT; ++rr) ND_GLDS16(qq + noff[rr], ring + ((gs & 1) * WNT + rr) * 256);
-    };
-
-    f32x16 acc[WNT];
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rr][e] = 0.f;
-
-    const int nchunks = p.NC32;
-    issue_halo(0, 0);
-    issue_b(0);
-    issue_b(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // VMEM issue order inside chunk ch (k-steps g = 4*ch + st):   st=0: B(g+2), H(ch+1) x2;  st=1..3: B(g+2).
-    // Before reading B(g) (issued two steps earlier) the younger operations allowed in flight are B(g+1) and whatever was
-    // issued between them:  st=0: 3;  st=1: 3 + 2 halo;  st=2: 2 halo + 3;  st=3: 3.
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* hbuf = smem + (ch & 1) * HBUF;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int gs = ch * 4 + st;
-            if (st == 0 || st == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            f32x4 bfr[WNT];
-#pragma unroll
-            for (int rr = 0; rr < WNT; ++rr)
-                bfr[rr] = *reinterpret_cast<const f32x4*>(ring + ((st & 1) * WNT + rr) * 256 + lane * 4);
-            const int kx = st << 3;
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(hbuf + (off4[0] ^ kx));
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(hbuf + (off4[1] ^ kx));
-            const f32x4 d2 = *reinterpret_cast<const f32x4*>(hbuf + (off4[2] ^ kx));
-            const f32x4 d3 = *reinterpret_cast<const f32x4*>(hbuf + (off4[3] ^ kx));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot (gs & 1) has been read: refill it
-            issue_b(gs + 2);                                       // (a partial lgkmcnt(4) here measured 10 % slower)
-            if (st == 0) issue_halo(ch + 1, (ch + 1) & 1);          // past the last chunk: zero block (c >= Ctot)
-            const f32x4 ta = d0 + sgr * d1;
-            const f32x4 tb = d2 + sgr * d3;
-            const f32x4 v = ta + sgc * tb;
-#pragma unroll
-            for (int rr = 0; rr < WNT; ++rr) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[rr][j], v[j], acc[rr], 0, 0, 0);
-            }
-        }
-        // next chunk's halo (issued at st = 0, followed by 9 weight DMAs) must have landed before anyone reads it
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // run-ahead weight DMAs still target the ring
-    __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue: identical to conv_wino16_kernel
-    const int g4r = wave & 3, pa = wave >> 3, pb = (wave >> 2) & 1;
-    const float sa = pa ? -1.f : 1.f, sb = pb ? -1.f : 1.f;
-    const int te = l31;
-    const int li = te >> (thl2 + twl2);
-    const int tyy = (te >> twl2) & ((1 << thl2) - 1);
-    const int txx = te & ((1 << twl2) - 1);
-    const int img = img0 + li;
-    const int oy = oy0 + 2 * tyy + pa, ox = ox0 + 2 * txx + pb;
-    const bool pix_ok = img < p.NI && oy < p.H && ox < p.W;
-    f32x4 resv[WNT];           // residual rows, fetched ahead of the LDS exchange (see conv_wino16_kernel)
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        resv[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nbr = n0 + rr * 32 + 8 * g4r + 4 * lh;
-        if (p.res && p.vec_ok && pix_ok && nbr + 3 < p.N) {
-            const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                        : ((size_t)(img * p.H + oy) * p.W + ox);
-            resv[rr] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nbr);
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < WNT; ++rr) {
-        {
-            float* exw = smem + (rr & 1) * (16 * 4 * 256);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 m = {acc[rr][4 * g4 + 0], acc[rr][4 * g4 + 1], acc[rr][4 * g4 + 2], acc[rr][4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(exw + ((wave * 4 + g4) * 64 + lane) * 4) = m;
-            }
-        }
-        __syncthreads();
-        {
-            const float* exr = smem + (rr & 1) * (16 * 4 * 256);
-            f32x4 rx[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int x2 = pa + i;
-                const f32x4 m0 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 0) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 1) * 4 + g4r) * 64 + lane) * 4);
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(exr + (((x2 * 4 + pb + 2) * 4 + g4r) * 64 + lane) * 4);
-                rx[i] = (m0 + sb * m1) + sb * m2;
-            }
-            f32x4 yv = (rx[0] + sa * rx[1]) + sa * rx[2];
-            const int nb = n0 + rr * 32 + 8 * g4r + 4 * lh;
-            if (pix_ok && nb < p.N) {
-                const bool vec = p.vec_ok && (nb + 3 < p.N);
-                float* op = p.out + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldo + nb;
-                const float* rp = nullptr;
-                if (p.res) {
-                    const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
-                                                : ((size_t)(img * p.H + oy) * p.W + ox);
-                    rp = p.res + rpx * p.ldr + nb;
-                }
-                if (vec) {
-                    if (p.bias) yv += *reinterpret_cast<const f32x4*>(p.bias + nb);
-                    if (p.rowbias) yv += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
-                    yv += resv[rr];
-                    if (p.silu_out) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) yv[c] = fast_silu(yv[c]);
-                    }
-                    *reinterpret_cast<f32x4*>(op) = yv;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (nb + c < p.N) {
-                            float v2 = yv[c];
-                            if (p.bias) v2 += p.bias[nb + c];
-                            if (p.rowbias) v2 += p.rowbias[(size_t)img * p.ld_rowbias + nb + c];
-                            if (rp) v2 += rp[c];
-                            if (p.silu_out) v2 = fast_silu(v2);
-                            op[c] = v2;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-#endif  // ND_EXPERIMENTAL_KERNELS
+// (Variants 9 / 10 / 11 -- LDS-DMA operand streams, the persistent form and the whole-transform-per-wave kernel -- were built,
+//  gave the same bits as conv_wino16_kernel and measured slower ("tried and rejected"); their code was removed in
+//  round 4 and lives in the git history.  Variant numbers are stable identifiers: retired ones are never reused.)
 
 // OIHW 3x3 weights -> Winograd domain U = G g G^T, fragment order [c32][n tile][kc][position][lane][4]
 __global__ void pack_wino_weight_kernel(const float* w, float* out, int N, int C, int NT32, long total) {
@@ -1448,8 +810,8 @@ extern "C" const char* nd_conv_winograd_variant_name(int variant) {
                                   "nd::conv_wino_kernel<1, 1, true, 2>",  "nd::conv_wino_kernel<1, 2, true, 2>",
                                   "nd::conv_wino_kernel<1, 2, false, 2>", "nd::conv_wino_kernel<1, 1, false, 1>",
                                   "nd::conv_wino_kernel<1, 2, false, 3>", "nd::conv_wino_kernel<1, 1, false, 3>",
-                                  "nd::conv_wino16_kernel<1>",            "nd::conv_wino16g_kernel",
-                                  "nd::conv_wino16p_kernel",              "nd::conv_winow_kernel",
+                                  "nd::conv_wino16_kernel<1>",            "(retired) nd::conv_wino16g_kernel",
+                                  "(retired) nd::conv_wino16p_kernel",    "(retired) nd::conv_winow_kernel",
                                   "nd::conv_wino4_kernel"};
     static_assert(sizeof(names) / sizeof(names[0]) == kNumWino, "one name per variant");
     return (variant < 0 || variant >= kNumWino) ? "" : names[variant];
@@ -1540,9 +902,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (residual) ND_REQUIRE(ldr >= N, fn, "ldr < N");
     if (rowbias) ND_REQUIRE(ld_rowbias >= N, fn, "ld_rowbias < N");
     ND_REQUIRE(variant >= 0 && variant < kNumWino, fn, "bad variant");
-#if !defined(ND_EXPERIMENTAL_KERNELS)
-    ND_REQUIRE(kWinoCfg[variant][3] < 5 || kWinoCfg[variant][3] > 7, fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
-#endif
+    ND_REQUIRE(kWinoCfg[variant][3] < 5 || kWinoCfg[variant][3] > 7, fn, "retired variant (its kernel was removed; see the git history)");
     ND_REQUIRE((long)NI * H * W < (1L << 31) / 2, fn, "too many pixels");
     const bool quad = kWinoCfg[variant][3] == 8;
     const bool wave16 = kWinoCfg[variant][3] == 7;
@@ -1597,7 +957,12 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         ND_REQUIRE((long)NI * (H >> up) * (W >> up) * ldx0 * 4 < (1L << 31) && (C1 == 0 || (long)NI * (H >> up) * (W >> up) * ldx1 * 4 < (1L << 31)), fn,
                    "the two-blocks-per-CU variant needs input tensors of less than 2 GiB");
         lds = (size_t)64 * 1024;          // two 28 KiB halo buffers; the epilogue exchange takes all 64 KiB (two blocks per CU)
-        if (const char* e = getenv("ND_W4_LDS_KB")) lds = (size_t)atoi(e) * 1024;      // diagnostics: > 80 forces one block per CU
+#if defined(ND_W4_DIAG)
+        // diagnostic builds only (tools/wino4_timeline.py): > 80 KiB forces one block per CU.  The epilogue exchange uses all
+        // 64 KiB, so less would be an out-of-bounds LDS access; more than 160 cannot launch
+        static const int diag_kb = [] { const char* e = getenv("ND_W4_LDS_KB"); const int v = e ? atoi(e) : 64; return v < 64 ? 64 : (v > 160 ? 160 : v); }();
+        lds = (size_t)diag_kb * 1024;
+#endif
     }
     if (persistent) {
         ND_REQUIRE((a.NC32 & 1) == 0, fn, "the persistent form needs an even number of 32-channel chunks");
@@ -1619,27 +984,6 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
         case 12: return launch_wino4(a, grid, lds, s);
-#if defined(ND_EXPERIMENTAL_KERNELS)
-        case 11: return launch_winow(a, grid, lds, s);
-        case 10: {
-            static bool attr_set[kMaxDevices] = {};
-            if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino16p_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-            const int pgrid = grid < cus ? grid : cus;      // one resident block per CU; every block's loop ends at the tile count
-            hipLaunchKernelGGL(conv_wino16p_kernel, dim3(pgrid), dim3(1024), lds, s, a);
-            return check_launch(fn);
-        }
-        case 9: {
-            static bool attr_set[kMaxDevices] = {};
-            if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino16g_kernel), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
-            hipLaunchKernelGGL(conv_wino16g_kernel, dim3(grid), dim3(1024), lds, s, a);
-            return check_launch(fn);
-        }
-#else
-        case 9: case 10: case 11:
-            return fail_arg(fn, "this variant is an experiment that is not built (make EXPERIMENTAL=1)");
-#endif
     }
     return fail_arg(fn, "bad variant");
 }

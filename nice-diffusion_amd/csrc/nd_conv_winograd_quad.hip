@@ -429,6 +429,12 @@ __global__ void __launch_bounds__(256, 2)
 #endif
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the halo buffers
     float* ex = smem;
+    // The lane id is derived AGAIN here (2 VALU) and everything the epilogue indexes by lane hangs off this value, so nothing
+    // lane-derived has to survive the main loop in a register: at 256 VGPRs hipcc kept lane & 15 / lane & 31 alive across the
+    // loop by spilling them to scratch (12 bytes, a scratch set-up per wave) instead of recomputing them.
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int l31e = lane_e & 31, lhe = lane_e >> 5;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -440,11 +446,11 @@ __global__ void __launch_bounds__(256, 2)
                 r0[ee] = acc[0][n][e] + acc[1][n][e] + acc[2][n][e];
                 r1[ee] = acc[1][n][e] - acc[2][n][e] - acc[3][n][e];
             }
-            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 0) * 4 + g4) * 64 + lane) * 4) = r0;
-            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 1) * 4 + g4) * 64 + lane) * 4) = r1;
+            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 0) * 4 + g4) * 64 + lane_e) * 4) = r0;
+            *reinterpret_cast<f32x4*>(ex + ((((n * 4 + xi) * 2 + 1) * 4 + g4) * 64 + lane_e) * 4) = r1;
         }
     }
-    const int te = l31;
+    const int te = l31e;
     const int li = te >> (thl2 + twl2);
     const int tyy = (te >> twl2) & ((1 << thl2) - 1);
     const int txx = te & ((1 << twl2) - 1);
@@ -458,13 +464,13 @@ __global__ void __launch_bounds__(256, 2)
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int nb = n0 + n * 32 + 8 * xi + 4 * lh;          // first of this lane's 4 output channels
+        const int nb = n0 + n * 32 + 8 * xi + 4 * lhe;          // first of this lane_e's 4 output channels
         f32x4 rr[4][2];
 #pragma unroll
         for (int x2 = 0; x2 < 4; ++x2)
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2)
-                rr[x2][b2] = *reinterpret_cast<const f32x4*>(ex + ((((n * 4 + x2) * 2 + b2) * 4 + xi) * 64 + lane) * 4);
+                rr[x2][b2] = *reinterpret_cast<const f32x4*>(ex + ((((n * 4 + x2) * 2 + b2) * 4 + xi) * 64 + lane_e) * 4);
         if (nb < p.N && img < p.NI) {
             const bool vec = p.vec_ok && (nb + 3 < p.N);
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -490,7 +496,7 @@ __global__ void __launch_bounds__(256, 2)
                         if (nb + c < p.N) rbv[c] = rbp[c];
                 }
             }
-            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};          // statistics of what this lane stores (p.chstats)
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};          // statistics of what this lane_e stores (p.chstats)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -560,10 +566,10 @@ __global__ void __launch_bounds__(256, 2)
             bool writer;
             if (gl == 32) {                             // DPP adds, no LDS traffic (nd_conv_common.h); total in lanes 16..31
                 sum8_over_32_lanes(fin, sq);
-                writer = l31 == 31;
+                writer = l31e == 31;
             } else if (gl == 16) {
                 sum8_over_16_lanes(fin, sq);
-                writer = (l31 & 15) == 0;
+                writer = (l31e & 15) == 0;
             } else {
                 for (int m = 1; m < gl; m <<= 1) {
 #pragma unroll
@@ -572,9 +578,9 @@ __global__ void __launch_bounds__(256, 2)
                         sq[c] += __shfl_xor(sq[c], m);
                     }
                 }
-                writer = (l31 & (gl - 1)) == 0;
+                writer = (l31e & (gl - 1)) == 0;
             }
-            const int nb = n0 + n * 32 + 8 * xi + 4 * lh;
+            const int nb = n0 + n * 32 + 8 * xi + 4 * lhe;
             if (writer && img < p.NI && nb < p.N) {
                 float* ps = p.chstats + (((size_t)img * p.mbi + mb) * 2) * p.N + nb;
                 if (nb + 3 < p.N && (p.N & 3) == 0) {

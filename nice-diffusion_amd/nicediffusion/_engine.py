@@ -32,20 +32,48 @@ def _tune_cache_path():
     return os.environ.get('ND_TUNE_CACHE')
 
 
+def _tune_stamp():
+    """What a file of measured choices is only valid for: the library's version and its variant tables (a choice is a
+    variant NUMBER; a rebuilt library may number its kernels differently)."""
+    lib = _hip.load()
+    names = [lib.nd_conv_winograd_variant_name(v).decode() for v in range(lib.nd_conv_winograd_num_variants())]
+    names += [lib.nd_conv_bf16_variant_name(v).decode() for v in range(lib.nd_conv_bf16_num_variants())]
+    return 'v{}:d{}:{}'.format(lib.nd_version(), lib.nd_conv_num_variants(), '|'.join(names))
+
+
+def preload_tune_cache(path, device_index=None, override=False):
+    """Take the measured choices of a file written by ``_save_tune_cache`` (committed ones live under profiles/): entries
+    are re-keyed to ``device_index`` (default: the current device) and skipped when this process already holds a choice
+    for the shape unless ``override``.  A file stamped by another library build is ignored.  Returns the number of
+    choices taken (0 if the file is missing, unreadable or stale)."""
+    try:
+        raw = json.load(open(path))
+    except (ValueError, OSError):
+        return 0
+    if raw.pop('__stamp__', None) != _tune_stamp():
+        print('[nd] tune cache {} was written by another library build: ignored'.format(path), file=sys.stderr)
+        return 0
+    if device_index is None:
+        device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    n = 0
+    for k, v in raw.items():
+        key = (device_index,) + tuple(json.loads(k))[1:]
+        if override or key not in _TUNED:
+            _TUNED[key] = tuple(v)
+            n += 1
+    return n
+
+
 def _load_tune_cache():
     """Optional on-disk cache of the measured choices (ND_TUNE_CACHE=file.json): lets a second process (e.g. a run under
     rocprofv3) start without the tuning launches."""
     path = _tune_cache_path()
     if path and os.path.exists(path) and not _TUNED:
-        try:
-            for k, v in json.load(open(path)).items():
-                _TUNED[tuple(json.loads(k))] = tuple(v)
-        except (ValueError, OSError):
-            pass
+        preload_tune_cache(path)
 
 
-def _save_tune_cache():
-    path = _tune_cache_path()
+def _save_tune_cache(path=None):
+    path = path or _tune_cache_path()
     if path:
         try:        # N ranks share the choices of rank 0 (parallel.tune_on_rank0): only that rank writes the file
             import torch.distributed as dist
@@ -53,7 +81,9 @@ def _save_tune_cache():
                 return
         except ImportError:
             pass
-        json.dump({json.dumps(list(k)): list(v) for k, v in _TUNED.items()}, open(path, 'w'))
+        out = {json.dumps(list(k)): list(v) for k, v in _TUNED.items()}
+        out['__stamp__'] = _tune_stamp()
+        json.dump(out, open(path, 'w'))
 
 
 def _pad4(n):
@@ -638,22 +668,7 @@ class UNetPlan:
                 best, best_ms = ('direct', v), ms
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
-            dma_ok = os.environ.get('ND_WINO_DMA', '0') == '1'
-            for v in range(self.lib.nd_conv_winograd_num_variants()):
-                # the LDS-DMA form measures 1 % slower than its register-staged sibling once the clock has settled: it is
-                # kept (and tested) as an explicit variant but is not a tuning candidate unless asked for
-                if not dma_ok and self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16g_kernel':
-                    continue
-                # the persistent form (one block per CU walking several tiles, next tile's first chunk prefetched) gives the
-                # same bits but measures 25-30 % slower: explicit variant, not a tuning candidate
-                if os.environ.get('ND_WINO_PERSISTENT', '0') != '1' and \
-                        self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino16p_kernel':
-                    continue
-                # the whole-transform-per-wave form (4 waves, output transform in registers) gives the same bits too and
-                # measures 20-40 % slower: one wave per SIMD cannot hide its own patch reads
-                if os.environ.get('ND_WINO_WAVE', '0') != '1' and \
-                        self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_winow_kernel':
-                    continue
+            for v in range(self.lib.nd_conv_winograd_num_variants()):      # (retired variant numbers refuse the launch)
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms

@@ -380,8 +380,9 @@ class Diffusion:
         The loop itself needs no communication (nothing on the path mixes samples)."""
         from .parallel import shard_slice, all_gather_rows
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return self.denoise(x=x, kwargs=kwargs, batch_size=x.shape[0], noise=noise, **kw)
+        # (a world of ONE still takes the sharded route: a one-GPU box runs the broadcast and the all-gather on RCCL)
         rank, world = dist.get_rank(), dist.get_world_size()
         sl = shard_slice(x.shape[0], rank, world)
         lk = None
@@ -397,7 +398,14 @@ class Diffusion:
         model = getattr(self, 'model', None)
         if model is not None and hasattr(model, '_plan') and getattr(self, 'device', torch.device('cpu')).type == 'cuda':
             from .parallel import tune_on_rank0
-            tune_on_rank0(model, sl.stop - sl.start)            # every rank runs the kernels rank 0 measured fastest
+            # every rank runs the kernels rank 0 measured fastest.  The plans are keyed by the FORWARD batch: rows of the
+            # shard, twice that under classifier-free guidance (_run_loop), and ragged shards have two sizes -- rank 0
+            # measures every one of them, so no rank tunes on its own
+            f = 2 if self.guidance == 'classifier_free' else 1
+            rows = [shard_slice(x.shape[0], r, world) for r in range(world)]
+            sizes = sorted({f * (s_.stop - s_.start) for s_ in rows if s_.stop > s_.start})
+            with torch.cuda.device(self.device):
+                tune_on_rank0(model, sizes, own=f * (rows[0].stop - rows[0].start))
         try:
             local = self.denoise(x=x[sl], kwargs=lk, batch_size=sl.stop - sl.start, noise=ln, **kw)
         finally:

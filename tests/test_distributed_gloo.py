@@ -104,6 +104,17 @@ def test_bench_multi_rank_branch_over_gloo():
     assert rec['config']['global_batch'] == 10 and rec['config']['per_gpu_batch'] == 5
     assert 'REHEARSAL' in rec['config']['parallelism'] and rec['vs_baseline'] is None
     assert abs(rec['value'] - 10 * 3 / (rec['ms_per_step'] * 3e-3)) / rec['value'] < 0.02      # whole-job images / MAX time
+    # what the backend saw (a future SCALE line must prove N ranks on N distinct devices): the process group's own world
+    # size, every rank's identity record and rows, its own chain and all-gather times
+    rk = rec['ranks']
+    assert rk['process_group'] == {'backend': 'gloo', 'world_size': 2}
+    assert [r['rank'] for r in rk['per_rank']] == [0, 1] and [r['rows'] for r in rk['per_rank']] == [[0, 5], [5, 10]]
+    assert all('host' in r and 'device' in r for r in rk['per_rank'])
+    assert all(set(r['chain_ms']) == {'min', 'median', 'max'} and set(r['all_gather_ms']) == {'min', 'median', 'max'}
+               for r in rk['per_rank'])
+    assert rk['chain_ms']['max'] >= rk['chain_ms']['min'] >= 0 and rk['all_gather_ms']['max'] > 0
+    assert rk['distinct_devices'] == 1            # both stub ranks report the host's 'cpu': ranks sharing a device are SEEN
+    assert rec['config']['unet_forwards_per_sampler_step'] == 1 and rec['config']['images_through_the_unet_per_sampler_step'] == 5
 
 
 def _tune_worker(rank, world, port, tmp, q):
@@ -118,12 +129,12 @@ def _tune_worker(rank, world, port, tmp, q):
         if rank == 0:       # what rank 0 measured on ITS device (ordinal 0)
             _engine._TUNED[(0, 64, 64, 64, 192, 192, 3, 0, True, False)] = ('wino', 12)
             _engine._TUNED[(0, 'bf16', 16, 8, 8, 1024, 1024, 3, 0, False, True, False, 'sk1', 'es1', 'gnnb')] = ('bf16+splitk', 19, 4)
-        else:               # a choice this rank already holds is kept
+        else:               # a different choice this rank already holds (earlier local tuning / cache file) LOSES to rank 0's
             _engine._TUNED[(5, 64, 64, 64, 192, 192, 3, 0, True, False)] = ('wino', 8)
         taken = share_tuned_choices(device_index=5 if rank else 0)
         _engine._save_tune_cache()          # only rank 0 may write the shared file
         dist.barrier()
-        q.put((rank, taken, sorted((list(map(str, k)), list(v)) for k, v in _engine._TUNED.items()),
+        q.put((rank, list(taken), sorted((list(map(str, k)), list(v)) for k, v in _engine._TUNED.items()),
                json.load(open(os.environ['ND_TUNE_CACHE']))))
     finally:
         dist.destroy_process_group()
@@ -131,8 +142,8 @@ def _tune_worker(rank, world, port, tmp, q):
 
 def test_rank0_tuning_is_shared_and_only_rank0_writes_the_cache(tmp_path):
     """parallel.share_tuned_choices: rank 0's measured kernel choices reach the other rank re-keyed to its device ordinal
-    (identical kernels on every rank => a sharded run is comparable bit for bit with the single-process one), an entry the
-    rank already holds is not overwritten, and ND_TUNE_CACHE is written by rank 0 alone."""
+    (identical kernels on every rank => a sharded run is comparable bit for bit with the single-process one), a different
+    entry the rank already holds is REPLACED by rank 0's (and counted), and ND_TUNE_CACHE is written by rank 0 alone."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -146,8 +157,9 @@ def test_rank0_tuning_is_shared_and_only_rank0_writes_the_cache(tmp_path):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert got[0][0] == 0 and got[1][0] == 1            # rank 1 took the bf16 choice, kept its own fp32 one
+    assert got[0][0] == [0, 0] and got[1][0] == [2, 1]  # rank 1 took both choices; one replaced a different local one
     keys1 = {tuple(k): v for k, v in got[1][1]}
-    assert keys1[tuple(map(str, (5, 64, 64, 64, 192, 192, 3, 0, True, False)))] == ['wino', 8]
+    assert keys1[tuple(map(str, (5, 64, 64, 64, 192, 192, 3, 0, True, False)))] == ['wino', 12]
     assert keys1[tuple(map(str, (5, 'bf16', 16, 8, 8, 1024, 1024, 3, 0, False, True, False, 'sk1', 'es1', 'gnnb')))] == ['bf16+splitk', 19, 4]
-    assert got[0][2] == got[1][2] and len(got[0][2]) == 2       # the file holds rank 0's two entries, whoever reads it
+    assert got[0][2] == got[1][2] and len(got[0][2]) == 3       # the file holds rank 0's two entries + the library stamp, whoever reads it
+    assert '__stamp__' in got[0][2]

@@ -119,8 +119,10 @@ def pack_wino(w):
     return out
 
 
-# kernels behind `make EXPERIMENTAL=1` (bit-identical, slower: DESIGN.md section 6); their variant numbers stay reserved
-EXPERIMENTAL_WINO = (b'nd::conv_wino16g_kernel', b'nd::conv_wino16p_kernel', b'nd::conv_winow_kernel')
+def retired(name):
+    """Variant numbers are stable identifiers; the kernels behind a retired one were removed (measured slower: DESIGN.md
+    section 6) and its launch is refused."""
+    return name.startswith(b'(retired)')
 
 
 WINO_CASES = [(2, 32, 32, 16, 16), (1, 64, 96, 8, 8), (3, 4, 32, 28, 28), (2, 96, 6, 16, 16), (1, 192, 192, 64, 64),
@@ -137,13 +139,9 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
         out = torch.full((B * H * W * Cout,), float('nan'), device=DEV)
         rc = lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                             None, 0, out.data_ptr(), Cout, B, H, W, Cout, 0, v, None, None, 0, st())
-        if rc != 0:      # the persistent form declines an odd number of 32-channel chunks, the 256-pixel whole-transform-per-wave
-            # form maps so small that 64 tiles span more than 416 halo pixels; the experiments are not in the default build
+        if rc != 0:
             name = lib().nd_conv_winograd_variant_name(v)
-            if name in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
-                continue
-            assert (name == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()) or \
-                (name == b'nd::conv_winow_kernel' and 'no tiling fits' in _hip.last_error() and H * W <= 16) or \
+            assert (retired(name) and 'retired variant' in _hip.last_error()) or \
                 (name == b'nd::conv_wino4_kernel' and 'whole 32-channel chunks' in _hip.last_error() and Cin % 32), (name, _hip.last_error())
             continue
         got = from_nhwc(out, B, H, W, Cout)
@@ -155,13 +153,11 @@ def test_conv3x3_winograd_all_variants(B, Cin, Cout, H, W):
     assert rc == -1 and 'even' in _hip.last_error()
 
 
-@pytest.mark.parametrize('other', [b'nd::conv_wino16p_kernel', b'nd::conv_winow_kernel', b'nd::conv_wino4_kernel'])
+@pytest.mark.parametrize('other', [b'nd::conv_wino4_kernel'])
 @pytest.mark.parametrize('B,Cin,Cout,H,W', [(8, 64, 192, 64, 64), (64, 128, 96, 8, 8), (3, 192, 200, 32, 32), (1, 64, 96, 16, 16)])
-def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W, other):
-    """conv_wino16p_kernel (one block per CU walking several tiles, the next tile's first chunk fetched during the current
-    tile's last one) and conv_winow_kernel (all 16 transform positions in one wave, output transform in registers) give
-    the SAME BITS as conv_wino16_kernel: several tiles per block, N tails, two-source input, per-image bias and residual
-    included."""
+def test_conv3x3_winograd_forms_give_the_same_bits(B, Cin, Cout, H, W, other):
+    """conv_wino4_kernel (row of the transform per wave, two blocks per CU) gives the SAME BITS as conv_wino16_kernel (one
+    position per wave): N tails, two-source input, per-image bias and residual included."""
     names = [lib().nd_conv_winograd_variant_name(v) for v in range(lib().nd_conv_winograd_num_variants())]
     v1, vp = names.index(b'nd::conv_wino16_kernel<1>'), names.index(other)
     C0 = Cin // 2
@@ -176,8 +172,6 @@ def test_conv3x3_winograd_persistent_matches_one_tile_form(B, Cin, Cout, H, W, o
         rc = lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, xbd.data_ptr(), Cin - C0, Cin - C0, wd.data_ptr(),
                                             bd.data_ptr(), rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(),
                                             Cout, B, H, W, Cout, 0, v, None, None, 0, st())
-        if rc != 0 and other in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
-            pytest.skip('experimental kernel: built with make EXPERIMENTAL=1 only')
         _hip.check(rc)
         outs.append(out.clone())
     assert torch.equal(outs[0], outs[1])
@@ -238,12 +232,10 @@ def test_conv3x3_winograd_fused_options():
                                             rbd.data_ptr(), Cout, resd.data_ptr(), Cout, out.data_ptr(), Cout, B, H, W,
                                             Cout, 0, v, None, None, 0, st())
         name = lib().nd_conv_winograd_variant_name(v)
-        if rc != 0 and name in EXPERIMENTAL_WINO and 'not built' in _hip.last_error():
+        if rc != 0:
+            assert retired(name) and 'retired variant' in _hip.last_error(), (name, _hip.last_error())
             continue
-        if rc != 0:      # 96 input channels = 3 chunks: the persistent form declines (it is covered by its own test)
-            assert name == b'nd::conv_wino16p_kernel' and 'even number' in _hip.last_error()
-        else:
-            assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
+        assert (from_nhwc(out, B, H, W, Cout) - ref).abs().max().item() < 2e-4
         out = torch.empty(B * 4 * H * W * Cout, device=DEV)
         _hip.check(lib().nd_conv3x3_winograd_nhwc(xd.data_ptr(), C0, C0, None, 0, 0, wd2.data_ptr(), bd.data_ptr(), None, 0,
                                                   rd.data_ptr(), Cout, out.data_ptr(), Cout, B, 2 * H, 2 * W, Cout,
@@ -401,7 +393,7 @@ def test_conv_with_fused_groupnorm(silu):
                                             cB.data_ptr(), C, st())
         if rc != 0:
             assert 'one image per block' in _hip.last_error() or 'do not fold GroupNorm' in _hip.last_error() or \
-                'not built' in _hip.last_error()
+                'retired variant' in _hip.last_error()
             continue
         err = (from_nhwc(out, B, H, W, Cout) - ref3).abs().max().item()
         assert err < 3e-4, (v, err)
@@ -426,11 +418,9 @@ GN_CASES = [(2, 32, 0, 16, 16), (3, 192, 0, 8, 8), (2, 64, 32, 7, 7), (1, 768, 7
             (2, 192, 0, 64, 64)]       # the last one spans many blocks per image: per-block partials + ticket path
 
 
-@pytest.mark.parametrize('B,C0,C1,H,W', GN_CASES)
-@pytest.mark.parametrize('mode', ['silu', 'plain', 'adagn', 'addvec', 'pool'])
+@pytest.mark.parametrize('B,C0,C1,H,W,mode', [c + (m_,) for c in GN_CASES for m_ in ('silu', 'plain', 'adagn', 'addvec', 'pool')
+                                              if not (m_ == 'pool' and (c[3] % 2 or c[4] % 2))])      # the pool needs even sizes
 def test_groupnorm(B, C0, C1, H, W, mode):
-    if mode == 'pool' and (H % 2 or W % 2):
-        pytest.skip('odd size')
     C = C0 + C1
     xa = rnd(B, C0, H, W, seed=1) * 2 + 0.5
     xb = rnd(B, C1, H, W, seed=2) if C1 else None
@@ -740,6 +730,36 @@ def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
     rc = lib().nd_conv3x3_winograd_stats_nhwc(xd.data_ptr(), Cin, Cin, None, 0, 0, wd.data_ptr(), bd.data_ptr(), None, 0,
                                               None, 0, out.data_ptr(), Cout + 4, B, H, W, Cout, 0, ps.data_ptr(), st())
     assert rc != 0
+
+
+@pytest.mark.parametrize('ratio', [1.0, 10.0, 30.0])
+def test_groupnorm_partial_rows_with_large_group_means(ratio):
+    """Precision of the default fp32 statistics route (per-channel partial ROWS rounded to fp32, re-grouped in float64:
+    nd_groupnorm_channel_partials_nhwc -> nd_groupnorm_stats_from_partials) against the float64 pass
+    (nd_groupnorm_stats_nhwc) when a group's mean is large against its spread.  var = E[x^2] - mean^2 formed
+    from fp32-rounded sums carries a relative error of about 2^-24 (1 + mean^2/var) per row, so the normalised output
+    stays within 8 * 2^-24 (1 + ratio^2) of the float64 route, ratio = |mean| / std of a group: < 1e-4 up to ratio ~ 10.  (UNet
+    activations sit at ratios of 0-3; ND_GN_PARTIALS=0 ND_GN_EPILOGUE_STATS=0 restores the float64 passes.)"""
+    B, C, H, W = 2, 192, 32, 32
+    x = rnd(B, C, H, W, seed=1) + ratio * (1 + 0.01 * rnd(1, C, 1, 1, seed=2))
+    xd = nhwc(x)
+    nb = lib().nd_groupnorm_stats_blocks(B, H * W, C, _hip.DT_F32)
+    rows = torch.full((B * nb * 2 * C,), float('nan'), device=DEV)
+    _hip.check(lib().nd_groupnorm_channel_partials_nhwc(xd.data_ptr(), C, C, rows.data_ptr(), B, H * W, _hip.DT_F32, st()))
+    a = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_from_partials(rows.data_ptr(), C, nb, None, 0, 0, a.data_ptr(), B, 32, st()))
+    b = gn_sums(*gn_stats(xd.data_ptr(), C, C, None, 0, 0, None, 0, B, H * W), B)
+    n = C // 32 * H * W
+
+    def mean_rstd(s):
+        mean = s[..., 0] / n
+        return mean, 1.0 / torch.sqrt(s[..., 1] / n - mean * mean + 1e-5)
+    (m_a, r_a), (m_b, r_b) = mean_rstd(a.view(B, 32, 2).cpu()), mean_rstd(b)
+    # what the apply kernel would output differs by |x - mean| * |rstd_a - rstd_b| + rstd * |mean_a - mean_b| (|x - mean| <= 5 std)
+    dy = (5.0 * (r_a - r_b).abs() / r_b + r_b * (m_a - m_b).abs()).max().item()
+    bound = 8 * 2.0 ** -24 * (1 + ratio * ratio)
+    print('ratio', ratio, 'output deviation of the fp32-row route', dy, 'bound', bound)
+    assert dy < max(bound, 2e-6) and (ratio > 10 or dy < 1e-4), (ratio, dy, bound)
 
 
 @pytest.mark.parametrize('B,C,N,H,W', [(2, 32, 48, 16, 16), (3, 64, 64, 8, 12)])

@@ -250,6 +250,73 @@ def test_weight_update_invalidates_plan():
     assert (m(x, t, y) - b).abs().max().item() < 1e-6          # weights restored
 
 
+def to_openai_names(sd):
+    """Inverse of utils.convert_state_dict (utils.py:265-292): this model's parameter names -> the names of
+    github.com/openai/guided-diffusion checkpoints (input_blocks / output_blocks / in_layers.N / emb_layers.1 / ...)."""
+    import collections
+    out = collections.OrderedDict()
+    for k, v in sd.items():
+        k = k.replace('downsampling', 'input_blocks').replace('upsampling', 'output_blocks')
+        k = k.replace('in_norm', 'in_layers.0').replace('in_conv', 'in_layers.2').replace('step_embedding', 'emb_layers.1')
+        k = k.replace('out_norm', 'out_layers.0').replace('out_conv', 'out_layers.3').replace('.skip.', '.skip_connection.')
+        k = k.replace('step_embed.', 'time_embed.').replace('qkv_nin', 'qkv').replace('class_embedding', 'label_emb')
+        out[k] = v
+    return out
+
+
+def test_openai_checkpoint_ingest_end_to_end(tmp_path, golden_dir):
+    """Row N1 as ONE path: a 64x64 checkpoint with openai/guided-diffusion parameter names on disk -> torch.load ->
+    utils.convert_state_dict (utils.py:265-292) -> load_state_dict(strict=True) (the load site of scripts/sample.py:43) ->
+    plan build (OIHW -> fragment-order repack) -> HIP forward == the reference's forward of the same weights
+    (fwd_preset_64.npz, generated from weights under THIS model's names)."""
+    from nicediffusion.utils import convert_state_dict
+    g = np.load(os.path.join(golden_dir, 'fwd_preset_64.npz'))
+    cfg = dict(DA.OPENAI_64_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    oa = to_openai_names(sd)
+    assert list(oa) != list(sd) and not any(k.startswith(('downsampling', 'upsampling', 'step_embed', 'class_embedding'))
+                                            for k in oa)
+    assert 'input_blocks.1.0.in_layers.2.weight' in oa and 'output_blocks.3.1.qkv.weight' in oa and \
+        'middle_block.0.emb_layers.1.bias' in oa and 'time_embed.2.bias' in oa and 'label_emb.weight' in oa
+    ckpt = str(tmp_path / '64x64_diffusion.pt')
+    torch.save(oa, ckpt)
+    del oa, sd
+    m = DiffusionModel(**cfg)
+    with pytest.raises(RuntimeError):                     # unconverted names do not load
+        m.load_state_dict(torch.load(ckpt, map_location='cpu'), strict=True)
+    m.load_state_dict(convert_state_dict(torch.load(ckpt, map_location='cpu')), strict=True)
+    m.to(DEV).eval()
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ('x', 't', 'y'))
+    err = np.abs(m(x, t, y).cpu().numpy() - g['out']).max()
+    assert err < 2e-4, err
+
+
+def test_trainer_sample_caller_shape_ema_ddpm_chain():
+    """The second caller of the path (trainer.py:35-36,117-134): ``sampling_diffusion`` = 250-step DDPM, called as
+    ``denoise(kwargs={'y': labels}, batch_size=4, ema_params=ema)`` with x=None (x_T drawn from torch's CPU generator) while
+    the model holds OTHER (training) weights.  Free-running over all 250 steps vs the oracle on the EMA weights with the
+    same x_T and per-step noise; afterwards the model's own weights are back."""
+    cfg = dict(TINY_CFGS['adagn_updown'])
+    m = build(cfg, seed=5)                                 # "training" weights
+    ema = {k: v.clone() for k, v in UO.synth_state_dict(cfg, seed=6).items()}
+    d = Diffusion(m, 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='linear', use_ddim=False, device=DEV)
+    labels = torch.tensor([3, 1, 4, 1])
+    torch.manual_seed(11)
+    noises = torch.randn(250, 4, 3, 16, 16)
+    torch.manual_seed(12)
+    got = d.denoise(kwargs={'y': labels.to(DEV)}, batch_size=4, ema_params=ema, progress=False, noise=noises).cpu()
+    torch.manual_seed(12)
+    xT = torch.randn(4, 3, 16, 16)                         # what denoise(x=None) drew (diffusion.py:199-201)
+    so = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(ema, cfg, a, b, c), DO.Schedule(1000, 250, 'linear'),
+                          'learned_interpolation', use_ddim=False)
+    ref = so.denoise(xT, labels, noises=noises)
+    err = (got - ref).abs().max().item()
+    assert err < 1e-3, err
+    x, t = torch.randn(1, 3, 16, 16), torch.tensor([7])
+    sd5 = UO.synth_state_dict(cfg, seed=5)
+    assert (m(x.to(DEV), t.to(DEV), labels[:1].to(DEV)).cpu() - UO.unet_forward(sd5, cfg, x, t, labels[:1])).abs().max().item() < 1e-4
+
+
 def test_in_place_weight_edits_and_repeated_ema_swaps_are_noticed():
     """Weights rewritten without a version bump (p.data.copy_) and two different EMA dicts in a row, whose temporaries the
     caching allocator hands the same addresses: the cached plan's repacked copies must not be reused."""
@@ -377,56 +444,196 @@ def test_groupnorm_statistics_routes_agree(monkeypatch):
     assert torch.equal(b, b2)          # and the default route is bitwise repeatable (no atomics anywhere)
 
 
-def test_sharded_denoise_two_ranks_one_gpu(tmp_path):
-    """denoise_sharded with two gloo ranks sharing cuda:0 (3 + 2 rows) reproduces the single-process run row by row,
-    including the in-kernel Philox noise of the DDPM sampler (each shard continues the global element count)."""
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+@pytest.mark.parametrize('backend,world,case', [('gloo', 2, 'tuned_cfg'), ('gloo', 2, 'tuned_ragged'), ('nccl', 1, 'tuned_cfg')])
+def test_sharded_denoise_ranks_on_one_gpu(tmp_path, backend, world, case):
+    """``denoise_sharded`` with the ranks sharing cuda:0: two gloo ranks (4 + 4 rows under classifier-free guidance = 8
+    forwards per rank and step; 3 + 2 rows = two shard sizes), and ONE rank over nccl = RCCL -- the one-GPU box's only way
+    to execute RCCL's init, ``broadcast_object_list`` of the tuned choices and ``all_gather_into_tensor``, with
+    HSA_ENABLE_IPC_MODE_LEGACY=0 as bench.py sets it.  The model is above the autotuner's threshold, so:
+      * every rank ends with the SAME measured kernel choices (rank 0's; plans are keyed by the forward batch, 2 x rows
+        under guidance -- ADVICE r3), for every shard size;
+      * each shard of the gathered result equals, bit for bit, a single process running those rows with those choices
+        (Philox keyed by the global element index, one seed);
+      * the whole result equals the single-process run of the global batch within fp32 summation order (another batch size
+        is another plan, possibly other kernel families)."""
+    import json
     import subprocess
     import sys
-    from oracle import unet_oracle as UO
+    from nicediffusion import _engine
+    from nicediffusion.parallel import shard_slice
+    from tests import shard_worker as SW
     out_path = str(tmp_path / 'sharded.pt')
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shard_worker.py')
-    port = str(29500 + (os.getpid() % 400))
-    procs = [subprocess.Popen([sys.executable, worker, str(r), '2', port, out_path]) for r in range(2)]
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, out_path, backend, case]) for r in range(world)]
     for p_ in procs:
-        assert p_.wait(timeout=300) == 0
+        assert p_.wait(timeout=600) == 0
     sharded = torch.load(out_path)
-    cfg = dict(TINY_CFGS['adagn_updown'])
-    m = build(cfg, seed=9)
-    d = Diffusion(m, 1000, 6, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=False, device=DEV)
-    d.seed = 4242
-    torch.manual_seed(0)
-    x = torch.randn(5, 3, 16, 16)
-    y = (torch.arange(5) * 3) % 10
-    single = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=5, progress=False).cpu()
-    assert sharded.shape == single.shape
-    # bit for bit: every rank runs the kernel variants rank 0 chose (parallel.tune_on_rank0), every kernel family sums in
-    # an order that does not depend on the batch size, and the Philox stream is keyed by the element's GLOBAL index
-    assert torch.equal(sharded, single), (sharded - single).abs().max().item()
+    choices = [json.load(open('{}.rank{}.json'.format(out_path, r))) for r in range(world)]
+    assert all(c == choices[0] for c in choices), 'ranks ran different kernel choices'
+    assert len(choices[0]) >= 4, 'nothing was tuned: the case does not exercise the hand-over'
+    c = SW.CASES[case]
+    f = 2 if c['guidance'] else 1
+    sizes = {f * (shard_slice(c['rows'], r, world).stop - shard_slice(c['rows'], r, world).start) for r in range(world)}
+    assert sizes <= {json.loads(k)[0] for k, _ in choices[0]}, 'a shard size has no measured choices'
+    for k, v in choices[0]:                       # this process runs rank 0's kernels too
+        _engine._TUNED[(0,) + tuple(tuple(e) if isinstance(e, list) else e for e in json.loads(k))] = tuple(v)
+    m, d, x, y = SW.build_case(case, 'cuda:0')
+    assert sharded.shape == x.shape
+    for r in range(world):
+        sl = shard_slice(c['rows'], r, world)
+        d.first_row = sl.start
+        part = d.denoise(x=x[sl], kwargs={'y': y[sl].to(DEV)}, batch_size=sl.stop - sl.start, progress=False).cpu()
+        assert torch.equal(sharded[sl], part), (r, (sharded[sl] - part).abs().max().item())
+    d.first_row = 0
+    single = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=c['rows'], progress=False).cpu()
+    assert (sharded - single).abs().max().item() < 1e-4
     # and the noise matters: a different seed moves the result by far more than that
     d.seed = 4243
-    other = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=5, progress=False).cpu()
+    other = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=c['rows'], progress=False).cpu()
     assert (other - single).abs().max().item() > 1e-2
 
 
-def test_full_size_properties_config2():
-    """BASELINE configs[1] shape (64x64 preset, B=64): size-independent properties instead of a CPU oracle run.
-    (a) rows are independent: a B=64 forward reproduces the B=2 forward of the same rows;
-    (b) one DDIM step is deterministic under graph replay;  (c) outputs are finite."""
-    m = build(dict(DA.OPENAI_64_MODEL_ARGS))
+def test_bench_one_rank_over_rccl():
+    """bench.py's N > 1 code with a world of ONE on the real backend (torchrun's environment, nccl = RCCL): process-group
+    init with device_id, the tuning hand-over, the all-gather inside the timed region, the MAX all-reduce, and the
+    identity record every rank contributes to the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    env.pop('ND_BENCH_BACKEND', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', 'config1', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-breakdown'], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    rk = rec['ranks']
+    assert rec['n_gpus'] == 1 and rk['process_group'] == {'backend': 'nccl', 'world_size': 1} and rk['distinct_devices'] == 1
+    me = rk['per_rank'][0]
+    assert me['rank'] == 0 and me['rows'] == [0, 4] and me['gcnArchName'].startswith('gfx950')
+    assert any(k in me for k in ('uuid', 'pci_bus_id')), me
+    assert rk['all_gather_ms']['max'] > 0 and rk['chain_ms']['min'] > 0
+    assert 'REHEARSAL' not in rec['config']['parallelism'] and rec['value'] > 0
+
+
+def _preload_committed_tune_cache(workload):
+    """The plan bench.py times is built from profiles/tune_cache_<workload>.json when that file matches the library: the
+    full-size tests pin THAT plan.  (Without a matching file both tune on the box, per layer, as before.)"""
+    from nicediffusion import _engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return _engine.preload_tune_cache(os.path.join(root, 'profiles', 'tune_cache_{}.json'.format(workload)), override=True)
+
+
+def test_full_size_config2_plan_vs_reference_rows_and_oracle(golden_dir):
+    """BASELINE configs[1] at the batch bench.py times (64x64 preset, B=64, bench.py's x_T / label recipe, the same
+    committed kernel choices).  The B=64 plan is the only one that runs what BENCH measures (other batch sizes pick other
+    tiles), so IT is put against the reference: rows 0 / 31 / 63 of (a) one forward and (b) one teacher-forced DDIM step of
+    the 250-step cosine chain vs the REAL reference's outputs for those rows (tests/golden/config2_headline_rows.npz,
+    tools/gen_golden.py gen_config2), plus one more row vs the CPU oracle run here; then (c) row independence against a
+    B=2 plan, and (d) bitwise repeatability of a 3-step chain under graph replay.  Tolerance 1e-3 (north_star); measured
+    ~2e-4, asserted at 5e-4."""
+    g = np.load(os.path.join(golden_dir, 'config2_headline_rows.npz'))
+    _preload_committed_tune_cache('config2')
+    cfg = dict(DA.OPENAI_64_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = DiffusionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).eval()
     torch.manual_seed(0)
     x = torch.randn(64, 3, 64, 64)
     y = (torch.arange(64) * 37) % 1000
     t = torch.full((64,), 498)
+    rows = torch.from_numpy(g['rows'])
     big = m(x.to(DEV), t.to(DEV), y.to(DEV))
     assert torch.isfinite(big).all()
-    idx = torch.tensor([0, 63])
-    small = m(x[idx].to(DEV), t[idx].to(DEV), y[idx].to(DEV))
-    assert (big[idx] - small).abs().max().item() < 1e-4
+    err = np.abs(big[rows].cpu().numpy() - g['out']).max()
+    assert err < 1e-3 and err < 5e-4, err                     # output absmax 0.63
+    orow = torch.tensor([17])
+    ref = UO.unet_forward(sd, cfg, x[orow], t[orow], y[orow])
+    err_o = (big[orow].cpu() - ref).abs().max().item()
+    assert err_o < 5e-4, err_o
+    small = m(x[rows[[0, 2]]].to(DEV), t[:2].to(DEV), y[rows[[0, 2]]].to(DEV))
+    assert (big[rows[[0, 2]]] - small).abs().max().item() < 1e-4
     d = Diffusion(m, 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0,
                   device=DEV)
+    first = int(g['ddim_first'])
+    step = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=1, first_index=first, progress=False)
+    err_s = np.abs(step[rows].cpu().numpy() - g['ddim_step']).max()
+    assert err_s < 5e-4, err_s
+    so = DO.SamplerOracle(lambda a, b_, c: UO.unet_forward(sd, cfg, a, b_, c), DO.Schedule(1000, 250, 'cosine'),
+                          'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    assert (step[orow].cpu() - so.ddim_step(x[orow], first, y[orow])[0]).abs().max().item() < 5e-4
     a = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     b = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    print('config2 B=64 plan: forward rows vs reference {:.2e}, vs oracle {:.2e}; DDIM step vs reference {:.2e}'.format(
+        err, err_o, err_s))
+
+
+def test_preset_64_own_25_step_ddim_chain_vs_reference(golden_dir):
+    """The 64x64 preset's OWN sampling configuration (default_args.py:15-21: 25-step DDIM, eta 0, cosine), free-running at
+    B=2 from x_T to x_0 through Diffusion.denoise (hipGraph replay), vs the REAL reference's trajectory after 1 / 5 / 13 / 25
+    steps on the same weights (sigma_zero = 0.005: contractive), x_T and labels."""
+    g = np.load(os.path.join(golden_dir, 'config2_headline_rows.npz'))
+    m = build(dict(DA.OPENAI_64_MODEL_ARGS))
+    d = Diffusion(model=m, **dict(DA.OPENAI_64_DIFFUSION_ARGS), device=DEV)
+    assert d.use_ddim and d.rescaled_num_steps == 25
+    torch.manual_seed(0)
+    x = torch.randn(64, 3, 64, 64)[:2]
+    y = ((torch.arange(64) * 37) % 1000)[:2]
+    out = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=2, progress=False)
+    err = np.abs(out.cpu().numpy() - g['chain_traj'][-1]).max()
+    assert err < 1e-3, err
+    tr = []
+    d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=2, progress=False, trace=tr)       # eager, with the trajectory
+    assert len(tr) == 25
+    errs = [float(np.abs(tr[int(k)].cpu().numpy() - g['chain_traj'][i]).max()) for i, k in enumerate(g['chain_keep'])]
+    assert max(errs) < 1e-3, errs
+    assert torch.equal(tr[-1], out)
+    print('64x64 preset, 25-step DDIM free-running vs reference after 1/5/13/25 steps:', ['%.2e' % e for e in errs])
+
+
+@pytest.mark.parametrize('name,pname,B,cfg', [('config4', 'OPENAI_128', 16, True), ('config5', 'OPENAI_256', 16, False)])
+def test_full_batch_fp32_forward_rows_vs_reference(golden_dir, name, pname, B, cfg):
+    """BASELINE configs[3] / [4] at their full per-GPU forward batch (32 = 2B under classifier-free guidance with the null
+    class in the second half; 16) in FP32: two rows of the full-batch plan's output vs the REAL reference's output for
+    those rows (strided sub-sample + mean / mean |.|, tools/gen_golden.py gen_large_rows).  The bf16 plans of the same
+    batches are put against the same vectors in tests/test_gpu_bf16.py."""
+    g = np.load(os.path.join(golden_dir, '{}_fullbatch_rows.npz'.format(name)))
+    margs = dict(getattr(DA, pname + '_MODEL_ARGS'))
+    if cfg:
+        margs['num_classes'] += 1
+    m = build(margs)
+    out = full_batch_forward(m, margs['resolution'], B, cfg, int(g['t'][0]))
+    rows, st = torch.from_numpy(g['rows']), int(g['stride'])
+    got = out[rows].cpu()
+    err = np.abs(got[:, :, ::st, ::st].numpy() - g['out_sub']).max()
+    assert err < 1e-3 and err < 5e-4, err
+    assert np.abs(got.mean(dim=(1, 2, 3)).numpy() - g['mean']).max() < 1e-5
+    assert np.abs(got.abs().mean(dim=(1, 2, 3)).numpy() - g['absmean']).max() < 1e-4
+    print(name, 'full-batch fp32 rows vs reference', err)
+
+
+def full_batch_forward(m, R, B, cfg, t):
+    """The forward batch of bench.py's workload: x_T = randn after manual_seed(0), labels (arange*37)%1000 (+1 and the
+    batch doubled as [x | x], [y | null class 0] under classifier-free guidance, diffusion.py:278-284)."""
+    torch.manual_seed(0)
+    x = torch.randn(B, 3, R, R)
+    y = (torch.arange(B) * 37) % 1000 + (1 if cfg else 0)
+    if cfg:
+        x, y = torch.cat([x, x]), torch.cat([y, torch.zeros_like(y)])
+    return m(x.to(DEV), torch.full((x.shape[0],), t).to(DEV), y.to(DEV))
 
 
 def test_config4_workload_fp32_ddpm_cfg_128():

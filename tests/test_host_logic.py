@@ -182,6 +182,46 @@ def test_convert_state_dict_names():
     assert list(out.values()) == list(sd.values())
 
 
+def test_convert_state_dict_whole_preset_key_tables(golden_dir):
+    """Every key of the four presets' state dicts (the REFERENCE's own key tables, preset_state_dicts.json), written with
+    openai/guided-diffusion names, comes back under the reference's name, in order, values untouched (utils.py:265-292)."""
+    import json as _json
+    meta = _json.load(open(os.path.join(golden_dir, 'preset_state_dicts.json')))
+    from tests.test_gpu_model import to_openai_names
+    for pname, rec in meta.items():
+        sd = {k: i for i, k in enumerate(rec['keys'])}
+        oa = to_openai_names(sd)
+        assert len(oa) == len(sd) and set(oa).isdisjoint(k for k in sd if not k.startswith(('middle_block', 'out.')))
+        assert all(k.split('.')[0] in ('input_blocks', 'middle_block', 'output_blocks', 'time_embed', 'label_emb', 'out')
+                   for k in oa), pname
+        back = convert_state_dict(oa)
+        assert list(back.keys()) == rec['keys'] and list(back.values()) == list(range(len(sd))), pname
+        assert list(oa.values()) == list(range(len(sd)))          # input untouched
+
+
+def test_hand_scheduled_kernels_have_no_scratch_and_fit_two_waves_per_simd():
+    """gemm4_kernel, gemm_bf16q_kernel and conv_wino4_kernel issue their run-ahead loads as inline ISA whose destination
+    registers are "in flight" until a hand-counted s_waitcnt: a spill or a copy of such a register by a future compiler /
+    flag change would read it before the data has landed (the pattern behind the run-to-run race fixed in round 3).  The
+    built library's own metadata must show no scratch, no spills and <= 256 VGPRs (two blocks of 4 waves per CU) for
+    every instantiation of the three kernels."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kernel_regs', os.path.join(root, 'tools', 'kernel_regs.py'))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    tab = kr.kernel_table(os.path.join(root, 'nice-diffusion_amd', 'nicediffusion', 'libnd_hip.so'))
+    assert len(tab) > 100
+    seen = set()
+    for name, r in tab.items():
+        for k in ('gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel'):
+            if 'nd::' + k in name:
+                seen.add(k)
+                assert r['scratch'] == 0 and r['sgpr_spill'] == 0 and r['vgpr_spill'] == 0, (name, r)
+                assert r['vgpr'] + r['agpr'] <= 256, (name, r)
+    assert seen == {'gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel'}, seen
+
+
 # ------------------------------------------------------------------------------------------------- sharding
 def test_shard_slice_partitions():
     for n in (1, 7, 64, 512, 513):

@@ -270,6 +270,94 @@ def gen_config1():
     save('config1_emnist_ddim50.npz', xT=xT.numpy(), y=y.numpy(), out=out.numpy(), u8=u8.numpy(), u8_saved=saved)
 
 
+# ------------------------------------------------------------------------------------------------ headline sizes
+HEADLINE_ROWS = (0, 31, 63)
+
+
+def gen_config2():
+    """BASELINE configs[1] at the batch bench.py times (64x64 preset, B=64, bench.py's x_T / label recipe): the REAL
+    reference on rows 0 / 31 / 63 of that batch -- one forward at t = 498 and one DDIM step at the first rescaled index
+    of the 250-step cosine chain -- and the preset's OWN sampling configuration (default_args.py:15-21: 25-step DDIM,
+    eta 0, cosine) free-running at B=2 with the contractive synthetic weights (sigma_zero = 0.005)."""
+    cfg = dict(ref_presets.OPENAI_64_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    torch.manual_seed(0)
+    x = torch.randn(64, 3, 64, 64)
+    y = (torch.arange(64) * 37) % 1000
+    idx = torch.tensor(HEADLINE_ROWS)
+    xr, yr = x[idx], y[idx]
+    t = torch.full((len(idx),), 498)
+    with torch.no_grad():
+        out = m(xr, t, yr)
+    o = UO.unet_forward(sd, cfg, xr, t, yr)
+    e = (o - out).abs().max().item()
+    print('   config2 rows forward oracle-vs-reference', e, 'absmax', out.abs().max().item())
+    assert e < 5e-5
+    d = Diffusion(m, 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0,
+                  device=torch.device('cpu'))
+    with torch.no_grad():
+        step, _ = d.ddim_denoising_step(xr, 249 * torch.ones(len(idx)), {'y': yr})
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, 250, 'cosine'),
+                          'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    e = (so.ddim_step(xr, 249, yr)[0] - step).abs().max().item()
+    print('   config2 rows DDIM step oracle-vs-reference', e)
+    assert e < 5e-5
+    # the preset's own chain
+    dargs = dict(ref_presets.OPENAI_64_DIFFUSION_ARGS)
+    d25 = Diffusion(model=m, **dargs, device=torch.device('cpu'))
+    assert d25.use_ddim and d25.rescaled_num_steps == 25
+    x2, y2 = x[:2].clone(), y[:2].clone()
+    keep = (0, 4, 12, 24)             # trajectory after 1, 5, 13 and all 25 steps
+    traj = []
+    xx = x2
+    with torch.no_grad():
+        for i, ts in enumerate(reversed(range(25))):
+            xx, _ = d25.ddim_denoising_step(xx, ts * torch.ones(2), {'y': y2})
+            if i in keep:
+                traj.append(xx.clone())
+        final = d25.denoise(x=x2, kwargs={'y': y2}, batch_size=2, progress=False)
+    assert torch.equal(final, traj[-1])
+    so25 = DO.SamplerOracle(lambda a, b, c: UO.unet_forward(sd, cfg, a, b, c), DO.Schedule(1000, 25, 'cosine'),
+                            'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    e = (so25.denoise(x2, y2) - final).abs().max().item()
+    print('   config2 preset 25-step DDIM chain oracle-vs-reference', e, 'absmax', final.abs().max().item())
+    assert e < 1e-3
+    save('config2_headline_rows.npz', rows=np.array(HEADLINE_ROWS), t=t.numpy(), out=out.numpy(), ddim_first=249,
+         ddim_step=step.numpy(), chain_keep=np.array(keep), chain_traj=torch.stack(traj).numpy())
+
+
+def gen_large_rows():
+    """Two rows of the full-batch forwards of BASELINE configs[3] (128x128 preset + null class, 2B = 32 forwards per step,
+    second half = the null class) and configs[4] (256x256 preset, B = 16) through the REAL reference in fp32.  Stored as a
+    strided sub-sample of the output plus its mean / mean |.| (the full tensors would be 0.8 / 3.1 MB)."""
+    for name, pre, ncls, NB, stride, rows in (('config4', 'OPENAI_128_MODEL_ARGS', 1001, 32, 2, (0, 31)),
+                                              ('config5', 'OPENAI_256_MODEL_ARGS', 1000, 16, 4, (0, 15))):
+        cfg = dict(getattr(ref_presets, pre))
+        cfg['num_classes'] = ncls
+        sd = UO.synth_state_dict(cfg, seed=1234)
+        m = ref_model(cfg, sd)
+        R = cfg['resolution']
+        torch.manual_seed(0)
+        B = NB // 2 if name == 'config4' else NB
+        x = torch.randn(B, 3, R, R)
+        y = (torch.arange(B) * 37) % 1000 + (1 if name == 'config4' else 0)
+        if name == 'config4':             # the classifier-free batch: [x | x], [y | null class 0]
+            x, y = torch.cat([x, x]), torch.cat([y, torch.zeros_like(y)])
+        idx = torch.tensor(rows)
+        t = torch.full((len(rows),), 321)
+        with torch.no_grad():
+            out = m(x[idx], t, y[idx])
+        o = UO.unet_forward(sd, cfg, x[idx], t, y[idx])
+        e = (o - out).abs().max().item()
+        print('  ', name, 'rows forward oracle-vs-reference', e, 'absmax', out.abs().max().item())
+        assert e < 1e-4
+        save('{}_fullbatch_rows.npz'.format(name), rows=np.array(rows), t=t.numpy(), stride=stride,
+             out_sub=out[:, :, ::stride, ::stride].numpy(), mean=out.mean(dim=(1, 2, 3)).numpy(),
+             absmean=out.abs().mean(dim=(1, 2, 3)).numpy())
+        del m, sd
+
+
 # ------------------------------------------------------------------------------------------------ N3: diffuse / img2img
 def gen_diffuse():
     """Reference Diffusion.diffuse (diffusion.py:133-153,232-240) and the --start_img chain of sample.py:54-64,76-78:
@@ -337,9 +425,10 @@ def gen_embed():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse']
+    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse', 'config2', 'large_rows']
     fns = dict(diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
-               samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets)
+               samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets, config2=gen_config2,
+               large_rows=gen_large_rows)
     for w in which:
         print('==', w)
         fns[w]()
