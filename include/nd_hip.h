@@ -246,6 +246,14 @@ int nd_groupnorm_channel_partials_nhwc(const void* x, int C, int ldx, float* row
                                        nd_stream_t stream);
 int nd_groupnorm_stats_from_partials(const float* p0, int C0, int rows0, const float* p1, int C1, int rows1,
                                      double* stats, int NI, int G, nd_stream_t stream);
+/* Statistics + apply in ONE launch for small tensors (launch-bound plans, e.g. the EMNIST preset at batch 4: replaces
+ * nd_groupnorm_channel_partials_nhwc + nd_groupnorm_stats_from_partials + nd_groupnorm_apply_nhwc; reference
+ * model.py:190,201-207,264,446-447 as above): one block per (group, image), float64 sums in a fixed order, the same
+ * coefficient arithmetic and flags (ND_GN_SILU, ND_GN_POOL2) as nd_groupnorm_apply_nhwc.  Channels per group <= 64. */
+int nd_groupnorm_fused_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                            const float* gamma, const float* beta, const float* scale, const float* shift, int ld_ss,
+                            void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,
+                            nd_stream_t stream);
 /* The same affine as nd_groupnorm_apply_nhwc as per-(image, channel) coefficients y = x*A + B, for convolutions
  * that apply it while loading their input (gnA/gnB of nd_conv_nhwc / nd_conv3x3_winograd_nhwc). */
 int nd_groupnorm_coeffs(const double* partials, int nblocks, const float* gamma, const float* beta, const float* scale,

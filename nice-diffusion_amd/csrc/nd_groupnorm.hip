@@ -320,6 +320,85 @@ __global__ void __launch_bounds__(GN_NT)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Small tensors (launch-bound plans: the EMNIST preset at batch 4 has 54 norms on tensors of 50-400 KB): statistics AND
+// apply in ONE launch.  One block per (group, image) reads its slab (HW pixels x C/G channels, a few KB, L2-resident)
+// twice: float64 sums in a fixed order (thread-strided items, then a fixed LDS tree: bitwise repeatable, no atomics),
+// the group's coefficients y = x * A[c] + B[c] in LDS with gn_apply_kernel's arithmetic, then the second pass writes the
+// normalised (+AdaGN, +SiLU, +2x2 average pool) tensor.  Replaces channel-partials + fold + apply (3 launches of ~6 us).
+template <typename T, bool POOL>
+__global__ void __launch_bounds__(256)
+    gn_fused_small_kernel(GnSrc<T> s, const float* gamma, const float* beta, const float* scale, const float* shift, int ld_ss,
+                          T* out, int ldo, int H, int W, int G, float eps, int silu) {
+    __shared__ double red[2][256];
+    __shared__ float cA[64], cB[64];                  // C / G <= GN_MAXCH / 32
+    const int g = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
+    const int C = s.C0 + s.C1;
+    const int cpg = C / G;
+    const int c_lo = g * cpg;
+    const int HW = H * W;
+    const int n = HW * cpg;
+    const size_t ibase = (size_t)img * HW;
+    double a = 0.0, b = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const int pix = i / cpg, c = c_lo + (i - pix * cpg);
+        const double v = (double)(float)*gn_ptr(s, ibase + pix, c);
+        a += v;
+        b += v * v;
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            red[0][t] += red[0][t + w];
+            red[1][t] += red[1][t + w];
+        }
+        __syncthreads();
+    }
+    if (t < cpg) {
+        const double inv_n = 1.0 / (double)n;
+        const double mean = red[0][0] * inv_n;
+        double var = red[1][0] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const int c = c_lo + t;
+        double ca = rstd * (double)gamma[c];
+        double cb = (double)beta[c] - mean * ca;
+        if (scale) {
+            const double sc = 1.0 + (double)scale[(size_t)img * ld_ss + c];
+            ca *= sc;
+            cb = cb * sc + (double)shift[(size_t)img * ld_ss + c];
+        }
+        cA[t] = (float)ca;
+        cB[t] = (float)cb;
+    }
+    __syncthreads();
+    const int Wo = POOL ? (W >> 1) : W, HWo = POOL ? (H >> 1) * Wo : HW;
+    const size_t obase = (size_t)img * HWo;
+    const int no = HWo * cpg;
+    for (int i = t; i < no; i += 256) {
+        const int po = i / cpg, cc = i - po * cpg, c = c_lo + cc;
+        const float ka = cA[cc], kb = cB[cc];
+        float y;
+        if (POOL) {
+            const int oy = po / Wo, ox = po - oy * Wo;
+            y = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = (float)*gn_ptr(s, ibase + (size_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1), c) * ka + kb;
+                if (silu) v = fast_silu(v);
+                y += v;
+            }
+            y *= 0.25f;
+        } else {
+            y = (float)*gn_ptr(s, ibase + po, c) * ka + kb;
+            if (silu) y = fast_silu(y);
+        }
+        out[(obase + po) * ldo + c] = (T)y;
+    }
+}
+
 // coefficients of the fused form: y = x * A[img][c] + B[img][c]  (consumed by the conv loaders)
 __global__ void __launch_bounds__(256)
     gn_coeffs_kernel(const double* partials, int nchunks, const float* gamma, const float* beta, const float* scale,
@@ -643,3 +722,30 @@ extern "C" int nd_groupnorm_coeffs_from_partials(const float* p0, int C0, int ro
     return check_launch(fn);
 }
 
+extern "C" int nd_groupnorm_fused_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                       const float* gamma, const float* beta, const float* scale, const float* shift, int ld_ss,
+                                       void* out, int ldo, int NI, int H, int W, int G, float eps, int flags, int dtype,
+                                       nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_fused_nhwc";
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    ND_REQUIRE(x0 && gamma && beta && out && NI > 0 && NI <= 65535 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && G > 0 && G <= 128 &&
+               (C0 + C1) % G == 0 && (C0 + C1) / G <= 64, fn, "bad arguments (channels per group <= 64)");
+    ND_REQUIRE(ldx0 >= C0 && (C1 == 0 || (x1 && ldx1 >= C1)) && ldo >= C0 + C1, fn, "strides");
+    ND_REQUIRE((scale == nullptr) == (shift == nullptr), fn, "scale and shift go together");
+    ND_REQUIRE((long)H * W * ((C0 + C1) / G) < (1L << 30), fn, "tensor too large for the one-launch form");
+    const bool pool = (flags & ND_GN_POOL2) != 0;
+    if (pool) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "POOL2 needs even H, W");
+    const int silu = (flags & ND_GN_SILU) ? 1 : 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(G, NI), blk(256);
+    if (dtype == ND_DT_BF16) {
+        GnSrc<__bf16> s{static_cast<const __bf16*>(x0), static_cast<const __bf16*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
+        if (pool) hipLaunchKernelGGL((gn_fused_small_kernel<__bf16, true>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<__bf16*>(out), ldo, H, W, G, eps, silu);
+        else hipLaunchKernelGGL((gn_fused_small_kernel<__bf16, false>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<__bf16*>(out), ldo, H, W, G, eps, silu);
+    } else {
+        GnSrc<float> s{static_cast<const float*>(x0), static_cast<const float*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
+        if (pool) hipLaunchKernelGGL((gn_fused_small_kernel<float, true>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<float*>(out), ldo, H, W, G, eps, silu);
+        else hipLaunchKernelGGL((gn_fused_small_kernel<float, false>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<float*>(out), ldo, H, W, G, eps, silu);
+    }
+    return check_launch(fn);
+}

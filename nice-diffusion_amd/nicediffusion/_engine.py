@@ -151,6 +151,14 @@ def _bf16_epilogue_stats():
     return int(os.environ.get('ND_BF16_EPILOGUE_STATS', '1'))
 
 
+def _gn_fused_max_elems():
+    """ND_GN_FUSED_MAX (default 2^20 elements = 4 MB of fp32): a GroupNorm over at most that many elements (images x pixels
+    x channels) takes ONE launch (nd_groupnorm_fused_nhwc: statistics + apply, one block per (group, image)) instead of
+    the per-channel partials pass, the fold and the apply pass.  Such plans are launch-bound (the EMNIST preset at batch
+    4: 257 -> 149 launches per forward); 0 switches the form off."""
+    return int(os.environ.get('ND_GN_FUSED_MAX', str(1 << 20)))
+
+
 def _bf16_splitk():
     """ND_BF16_SPLITK (default 1): bf16 convs on small maps (<= 8192 output pixels, >= 512 input channels) are also measured
     split over K (nd_conv_bf16_splitk_nhwc, 2 and 4 splits) and run that way where it is faster; 0: never; 2: wherever a
@@ -694,6 +702,15 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
+        if NI * H * W * C <= _gn_fused_max_elems() and C // GN_GROUPS <= 64 and (not pool or (H % 2 == 0 and W % 2 == 0)):
+            # small tensor: statistics and apply in one launch; the normalised tensor is materialised
+            out = self._new(NI, H // 2 if pool else H, W // 2 if pool else W, C)
+            flags = (_hip.GN_SILU if silu else 0) | (_hip.GN_POOL2 if pool else 0)
+            self._emit(self.lib.nd_groupnorm_fused_nhwc,
+                       [src.ptr, src.C, src.ld, s2[0], s2[1], s2[2], norm.weight.detach().data_ptr(),
+                        norm.bias.detach().data_ptr(), scale_ptr, shift_ptr, ld_ss, out.ptr, out.ld, NI, H, W, GN_GROUPS, GN_EPS,
+                        flags, self.dt], label + '.fused')
+            return out
         # a concatenation of which ONE half carries epilogue statistics (the skip tensor of a Downsample layer has none): the
         # other half gets its rows from a pass over that half alone, so the rows the producing conv paid for are used and the
         # statistics pass does not re-read the half that has them (the tuner credits the '+stats' conv with that pass)
@@ -814,6 +831,7 @@ class UNetPlan:
         out_act = Act(self.out, NI, R, R, self.Cout, self.Cout_p)      # fp32 in both modes
         self.conv(h, m.out[2].weight, m.out[2].bias.detach().data_ptr(), self.Cout, 3,
                   out=out_act, label='conv3x3')
+        self._release(h)
         self._release(x_cur)
 
         # ---- GroupNorm partial-statistics arena (float64; per norm [NI][blocks][32][2], fully written by every forward:

@@ -52,6 +52,7 @@ SIGNATURES = {
     'nd_groupnorm_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     'nd_groupnorm_apply_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i,
                                 _i, _i, _i, _i, _f, _i, _i, _vp],
+    'nd_groupnorm_fused_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
     'nd_conv_bf16_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                           _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_conv3x3_bf16_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,

@@ -732,6 +732,68 @@ def test_conv_winograd_epilogue_statistics(B, Cin, Cout, H, W):
     assert rc != 0
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,C0,C1,H,W,mode', [(4, 64, 0, 28, 28, 'silu'), (4, 128, 128, 14, 14, 'adagn'), (3, 256, 128, 7, 7, 'adagn'),
+                                              (2, 64, 32, 7, 7, 'plain'), (4, 128, 0, 14, 14, 'pool'), (2, 32, 0, 16, 16, 'pool'),
+                                              (1, 2048, 0, 4, 4, 'silu'), (2, 96, 0, 16, 12, 'adagn')])
+def test_groupnorm_fused_one_launch(B, C0, C1, H, W, mode, dtype):
+    """nd_groupnorm_fused_nhwc (statistics + apply in one launch, the small-tensor form of launch-bound plans) vs
+    F.group_norm (+AdaGN affine, +SiLU, +2x2 average pool; model.py:190,201-207,111), two-source input included, and vs the
+    three-launch route (float64 statistics pass + apply): same coefficient arithmetic, so fp32 results agree to 1e-6."""
+    bf = dtype == 'bf16'
+    C = C0 + C1
+    q = (lambda t_: t_.to(torch.bfloat16).float()) if bf else (lambda t_: t_)
+    xa = q(rnd(B, C0, H, W, seed=1) * 2 + 0.5)
+    xb = q(rnd(B, C1, H, W, seed=2)) if C1 else None
+    x = torch.cat([xa, xb], 1) if C1 else xa
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    scale, shift = 0.3 * rnd(B, C, seed=5), 0.3 * rnd(B, C, seed=6)
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
+    if mode == 'adagn':
+        ref = ref * (1 + scale.double()[:, :, None, None]) + shift.double()[:, :, None, None]
+    if mode != 'plain':
+        ref = F.silu(ref)
+    if mode == 'pool':
+        ref = F.avg_pool2d(ref, 2, 2)
+    ref = ref.float()
+    dt = _hip.DT_BF16 if bf else _hip.DT_F32
+    tdt = torch.bfloat16 if bf else torch.float32
+
+    def dev_nhwc(t_):
+        return t_.permute(0, 2, 3, 1).contiguous().to(tdt).to(DEV)
+    xad, xbd = dev_nhwc(xa), (dev_nhwc(xb) if C1 else None)
+    p = lambda t_: None if t_ is None else t_.data_ptr()
+    sc, sh = (scale.to(DEV), shift.to(DEV)) if mode == 'adagn' else (None, None)
+    Ho, Wo = (H // 2, W // 2) if mode == 'pool' else (H, W)
+    flags = (0 if mode == 'plain' else _hip.GN_SILU) | (_hip.GN_POOL2 if mode == 'pool' else 0)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    out = torch.full((B * Ho * Wo * C,), float('nan'), dtype=tdt, device=DEV)
+    _hip.check(lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C,
+                                             out.data_ptr(), C, B, H, W, 32, 1e-5, flags, dt, st()))
+    got = out.view(B, Ho, Wo, C).permute(0, 3, 1, 2).float().cpu()
+    tol = (2.0 ** -8 * ref.abs() + 1e-3) if bf else torch.full_like(ref, 2e-5)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+    out2 = torch.full_like(out, float('nan'))
+    _hip.check(lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C,
+                                             out2.data_ptr(), C, B, H, W, 32, 1e-5, flags, dt, st()))
+    assert torch.equal(out, out2)                    # fixed-order sums: bitwise repeatable
+    # the three-launch route on the same input
+    stats, nb = gn_stats(xad.data_ptr(), C0, C0, p(xbd), C1, C1, None, 0, B, H * W, dtype=dt)
+    out3 = torch.full_like(out, float('nan'))
+    _hip.check(lib().nd_groupnorm_apply_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, None, 0, stats.data_ptr(), nb, gd.data_ptr(),
+                                             bd.data_ptr(), p(sc), p(sh), C, out3.data_ptr(), C, B, H, W, 32, 1e-5, flags, dt, st()))
+    d3 = (out.float() - out3.float()).abs().max().item()
+    assert d3 <= (2.0 ** -7 * ref.abs().max().item() if bf else 1e-6), d3
+    # more than 64 channels per group are refused before anything is launched (G = 1 makes every case here too wide or, for
+    # C <= 64, is simply not called: `out` is sized for THIS case's flags), and so is a pool over odd sizes
+    if C > 64:
+        assert lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), None, None, 0,
+                                             out.data_ptr(), C, B, H, W, 1, 1e-5, flags, dt, st()) != 0
+    if H % 2:
+        assert lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), None, None, 0,
+                                             out.data_ptr(), C, B, H, W, 32, 1e-5, _hip.GN_POOL2, dt, st()) != 0
+
+
 @pytest.mark.parametrize('ratio', [1.0, 10.0, 30.0])
 def test_groupnorm_partial_rows_with_large_group_means(ratio):
     """Precision of the default fp32 statistics route (per-channel partial ROWS rounded to fp32, re-grouped in float64:

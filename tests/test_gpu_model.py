@@ -405,6 +405,9 @@ def test_groupnorm_statistics_routes_agree(monkeypatch):
 
     def names():
         return [f.__name__ for f, _, _ in m._plan(16).ops]
+    # (this model's 16x16 tensors are small enough for the one-launch form of launch-bound plans: switched off here, the
+    # routes under test are the large-tensor ones; the one-launch form is compared with them at the end)
+    monkeypatch.setenv('ND_GN_FUSED_MAX', '0')
     monkeypatch.setenv('ND_GN_PARTIALS', '0')
     monkeypatch.setenv('ND_GN_EPILOGUE_STATS', '0')
     m._plans = {}
@@ -442,6 +445,13 @@ def test_groupnorm_statistics_routes_agree(monkeypatch):
     assert 'nd_conv3x3_winograd_vstats_nhwc' in nc, 'no conv left statistics behind (the tuner chose other kernels for every conv)'
     b2 = m(x, t, y)
     assert torch.equal(b, b2)          # and the default route is bitwise repeatable (no atomics anywhere)
+    monkeypatch.setenv('ND_GN_FUSED_MAX', str(1 << 30))      # every norm by nd_groupnorm_fused_nhwc: same forward
+    m._plans = {}
+    e = m(x, t, y).clone()
+    ne = names()
+    m._plans = {}
+    assert ne.count('nd_groupnorm_fused_nhwc') == na.count('nd_groupnorm_stats_nhwc') and 'nd_groupnorm_apply_nhwc' not in ne
+    assert (a - e).abs().max().item() < tol and torch.equal(e, m(x, t, y))
 
 
 def _free_port():
