@@ -94,6 +94,18 @@ int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int
 int nd_conv_num_variants(void);
 /* The variant nd_conv_nhwc picks for a shape when `variant` < 0 (host-only query; < 0 on error), and a variant's
  * block tile (pixels x output channels) and thread count.  Used by bench.py to attribute launches to kernels. */
+/* The same convolution split over K, for layers whose output has too few tiles to fill the chip and whose contraction is
+ * long (7x7 .. 16x16 maps at small batch; the reference runs them as ordinary Conv2d, model.py:166-182): `splits` (2..16)
+ * block rows each run a range of whole 32-channel chunks of the (concatenated) input and leave raw accumulators in
+ * `workspace` (nd_conv_splitk_workspace_floats() floats, 16-byte aligned); a second launch adds them IN SPLIT ORDER and
+ * applies bias / per-image bias / residual / SiLU -- deterministic, no atomics.  conv_mfma_kernel variants (0..8) only,
+ * named explicitly; no fused GroupNorm, no ND_CONV_RES_UP2X; C0 + C1 a multiple of 32, N and the strides of 4. */
+int nd_conv_splitk_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                        const float* residual, int ldr, float* out, int ldo,
+                        int NI, int H, int W, int N, int ksize, int flags, int variant, int splits,
+                        float* workspace, nd_stream_t stream);
+int64_t nd_conv_splitk_workspace_floats(int NI, int H, int W, int N, int C, int ksize, int splits);
 int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias);
 int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);
 

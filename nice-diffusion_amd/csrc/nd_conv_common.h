@@ -44,7 +44,41 @@ struct ConvArgs {
     const float* gnA;
     const float* gnB;
     int ld_gn, gn_silu, gn_hw;    // gn_hw > 0: flat pixel list, image = pixel / gn_hw
+    // split over K (conv_mfma_kernel only; nd_conv_splitk_nhwc): block row s = blockIdx.y runs the channel-chunk range of
+    // split s and leaves raw accumulators in out + s * ws_stride; 0 / 1 = one pass
+    int ksplit, kchunks;
+    long ws_stride;
 };
+
+// The arguments of split s, derived from the whole problem's: a convolution over the 32-channel chunks
+// [s * kchunks, (s + 1) * kchunks) of the (concatenated) input.  The packed weights are chunk-major
+// ([c32][n tile][tap][k-step][lane][4]), so a split's weights are a contiguous range too.
+__device__ __forceinline__ void split_k_args_f32(ConvArgs& p, int s, int taps) {
+    const int span = p.kchunks * 32;
+    const int c_begin = s * span;
+    int nc = p.NC32 - s * p.kchunks;
+    nc = nc < p.kchunks ? nc : p.kchunks;
+    p.w += (size_t)s * p.kchunks * ((size_t)p.NT32 * taps * 4 * 256);
+    if (c_begin < p.C0) {
+        p.x0 += c_begin;
+        const int left0 = p.C0 - c_begin;
+        if (left0 >= span) {
+            p.C0 = span;
+            p.C1 = 0;
+        } else {                                  // the concatenation seam lies inside this split's range
+            p.C0 = left0;
+            p.C1 = (p.C1 < span - left0) ? p.C1 : span - left0;
+        }
+    } else {
+        const int off1 = c_begin - p.C0;
+        p.x0 = p.x1 + off1;
+        p.ldx0 = p.ldx1;
+        p.C0 = (p.C1 - off1 < span) ? p.C1 - off1 : span;
+        p.C1 = 0;
+    }
+    p.NC32 = nc;
+    p.out += (size_t)s * p.ws_stride;
+}
 
 // Block -> tile order.  The n tiles are taken in groups of `ngroup`; inside a group the walk is m-major with n fastest,
 // so the blocks resident at one time on an XCD (consecutive ids) cover a few m tiles x ngroup n tiles: each input tile is

@@ -29,7 +29,9 @@ namespace nd {
 
 template <int WM, int WN, int TM, int TN, int TAPS, int OCC>
 __global__ void __launch_bounds__(WM* WN * 64, OCC)
-    conv_mfma_kernel(const ConvArgs p) {
+    conv_mfma_kernel(const ConvArgs pin) {
+    ConvArgs p = pin;
+    if (pin.ksplit > 1) split_k_args_f32(p, blockIdx.y, TAPS);
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -405,6 +407,30 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
     }
 }
 
+// Split-K second pass (nd_conv_splitk_nhwc): out[m][n] = sum_s ws[s][m][n] + bias[n] + rowbias[img(m)][n] + residual[m][n]
+// (SiLU last), the partials added in split order and then in the one-pass kernel's association: deterministic.  One
+// thread per 4 channels.
+__global__ void __launch_bounds__(256)
+    splitk_reduce_f32_kernel(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
+                             int ld_rowbias, int hw, const float* res, int ldr, float* out, int ldo, int silu) {
+    const int nq = N >> 2;
+    const long total = M * nq;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long m = it / nq;
+        const int n = (int)(it - m * nq) << 2;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (size_t)s * ws_stride + m * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (rowbias) v += *reinterpret_cast<const f32x4*>(rowbias + (m / hw) * ld_rowbias + n);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + m * ldr + n);
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+        }
+        *reinterpret_cast<f32x4*>(out + m * ldo + n) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 1x1 "stream" form (flat pixel list only): a 1x1 convolution is a plain GEMM, and with K = Cin of a few hundred a
 // block lives for ~12 chunks -- too short to amortise the LDS staging + barrier per chunk of the kernel above.  Here
@@ -662,7 +688,7 @@ static int launch_variant(const ConvArgs& a, int grid, size_t lds, hipStream_t s
     auto kern = conv_mfma_kernel<WM, WN, TM, TN, TAPS, (OCC * WM * WN + 3) / 4>;
     static bool attr_set[kMaxDevices] = {};
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WM * WN * 64), lds, s, a);
     return check_launch("nd_conv_nhwc");
     }
 }
@@ -792,12 +818,22 @@ extern "C" int nd_repack_conv_weight(const float* w, float* w_out, int N, int C,
     return check_launch(fn);
 }
 
-extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
-                            const float* w, const float* bias, const float* rowbias, int ld_rowbias,
-                            const float* residual, int ldr, float* out, int ldo,
-                            int NI, int H, int W, int N, int ksize, int flags, int variant,
-                            const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
-    const char* fn = "nd_conv_nhwc";
+// the split plan shared by conv_f32_impl and nd_conv_splitk_workspace_floats: whole LDS chunks per split (32 channels for
+// 3x3, pairs of them for 1x1); returns the number of splits actually used (< 2: cannot split) and the chunks per split
+static int splitk_plan_f32(int C, int ksize, int splits, int* kchunks) {
+    const int nc32 = (C + 31) / 32, unit = ksize == 3 ? 1 : 2;
+    int kc = (nc32 + splits - 1) / splits;
+    kc = (kc + unit - 1) / unit * unit;
+    *kchunks = kc;
+    return (nc32 + kc - 1) / kc;
+}
+
+static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                         const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                         const float* residual, int ldr, float* out, int ldo,
+                         int NI, int H, int W, int N, int ksize, int flags, int variant,
+                         const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream, int splits = 1,
+                         float* workspace = nullptr) {
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -820,7 +856,8 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     const int taps = ksize * ksize;
     const long M = (long)NI * H * W;
     int pNI = NI, pH = H, pW = W;
-    const bool flat = use_flat(taps, flags, rowbias);
+    // (a split launch leaves the per-image bias to its reduce pass, so it may use the dense flat pixel list)
+    const bool flat = use_flat(taps, flags, splits > 1 ? nullptr : rowbias);
     if (flat) { pNI = 1; pH = 1; pW = (int)M; }
 
     ND_REQUIRE(variant < kNumVariants, fn, "bad variant");
@@ -839,12 +876,29 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
 
     const Variant& V = kVariants[best_v];
     ConvArgs a;
+    a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;
+    if (splits > 1) {
+        // block row s runs the channel range of split s and leaves raw accumulators in the workspace;
+        // splitk_reduce_f32_kernel finishes the layer (bias, per-image bias, residual, SiLU)
+        ND_REQUIRE(workspace != nullptr && aligned16(workspace) && !stream_form && gnA == nullptr, fn,
+                   "split-K: needs a 16-byte aligned workspace; conv_mfma_kernel variants only; no fused GroupNorm");
+        ND_REQUIRE(!res_up && (N & 3) == 0 && (ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                   (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
+                   (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias))), fn,
+                   "split-K: N and the strides must be multiples of 4 with 16-byte aligned pointers; no 2x-upsampled residual");
+        ND_REQUIRE(((C0 + C1) & 31) == 0 && (C1 == 0 || (C0 & 3) == 0), fn, "split-K: whole 32-channel chunks");
+        int kc = 0;
+        const int S = splitk_plan_f32(C0 + C1, ksize, splits, &kc);
+        ND_REQUIRE(S > 1, fn, "split-K: too few input channels for that many splits");
+        a.ksplit = S; a.kchunks = kc; a.ws_stride = M * N;
+    }
     a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
+    if (a.ksplit > 1) { a.bias = nullptr; a.rowbias = nullptr; a.res = nullptr; a.out = workspace; }
     a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
     a.NI = pNI; a.H = pH; a.W = pW;
     a.up = up; a.res_up = res_up;
     a.Hs = pH >> up; a.Ws = pW >> up;
-    a.N = N; a.ldo = ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
+    a.N = N; a.ldo = (a.ksplit > 1) ? N : ldo; a.ldr = ldr; a.ld_rowbias = ld_rowbias;
     a.NT32 = (N + 31) / 32;
     a.NC32 = (C0 + C1 + 31) / 32;
     a.thl = best_tp.thl; a.twl = best_tp.twl; a.nibl = best_tp.nibl;
@@ -853,7 +907,7 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float), (size_t)M * (C0 + C1) * sizeof(float));
     a.vec_ok = 0; a.nhi = 0; a.zero = nullptr; a.chstats = nullptr; a.mbi = 1;
-    a.silu_out = (flags & ND_CONV_SILU_OUT) ? 1 : 0;
+    a.silu_out = ((flags & ND_CONV_SILU_OUT) && a.ksplit <= 1) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
         // one image per block, so that a thread's coefficient pair is fixed per chunk
@@ -885,7 +939,49 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
                        "the two-blocks-per-CU GEMM needs input tensors of less than 2 GiB");
             return launch_gemm4(a, grid, s);
     }
-    return (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
+    const int rc = (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
+    if (rc != ND_OK || a.ksplit <= 1) return rc;
+    const long quads = M * (N >> 2);
+    long rg = (quads + 255) / 256;
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((int)rg), dim3(256), 0, s, workspace, a.ksplit, a.ws_stride, M, N, bias, rowbias,
+                       ld_rowbias, H * W, residual, ldr, out, ldo, (flags & ND_CONV_SILU_OUT) ? 1 : 0);
+    return check_launch(fn);
+}
+
+extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                            const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                            const float* residual, int ldr, float* out, int ldo,
+                            int NI, int H, int W, int N, int ksize, int flags, int variant,
+                            const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
+    return conv_f32_impl("nd_conv_nhwc", x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W,
+                         N, ksize, flags, variant, gnA, gnB, ld_gn, stream);
+}
+
+// The same convolution split over K: `splits` (2..16) block rows each run a range of 32-channel chunks of the input and
+// leave raw accumulators in `workspace` (nd_conv_splitk_workspace_floats() floats); a second launch adds them in split
+// order and applies bias / per-image bias / residual / SiLU.  For layers whose output has too few tiles to fill the chip
+// and whose contraction is long (7x7 .. 16x16 maps at small batch); conv_mfma_kernel variants (0..8) only, named explicitly.
+extern "C" int nd_conv_splitk_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                   const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                   const float* residual, int ldr, float* out, int ldo,
+                                   int NI, int H, int W, int N, int ksize, int flags, int variant, int splits,
+                                   float* workspace, nd_stream_t stream) {
+    const char* fn = "nd_conv_splitk_nhwc";
+    ND_REQUIRE(splits >= 2 && splits <= 16 && workspace != nullptr && variant >= 0 && variant < kFirstStream, fn,
+               "2..16 splits, a workspace of nd_conv_splitk_workspace_floats() floats, and a named conv_mfma_kernel variant");
+    return conv_f32_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N, ksize,
+                         flags, variant, nullptr, nullptr, 0, stream, splits, workspace);
+}
+
+// fp32 words nd_conv_splitk_nhwc writes to (and its reduce kernel reads from) `workspace`: one [NI*H*W][N] slab of raw
+// accumulators per split actually used -- fewer than asked for when the layer has fewer chunks
+extern "C" int64_t nd_conv_splitk_workspace_floats(int NI, int H, int W, int N, int C, int ksize, int splits) {
+    if (NI <= 0 || H <= 0 || W <= 0 || N <= 0 || C <= 0 || (ksize != 1 && ksize != 3) || splits < 2 || splits > 16) return ND_E_ARG;
+    int kc = 0;
+    const int S = splitk_plan_f32(C, ksize, splits, &kc);
+    if (S < 2) return ND_E_ARG;
+    return (int64_t)S * NI * H * W * N;
 }
 
 extern "C" int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias) {

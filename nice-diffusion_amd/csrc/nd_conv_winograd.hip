@@ -919,6 +919,7 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (!found) return fail_arg(fn, "no tiling fits this shape");
     const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
     ConvArgs a;
+    a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;      // (split-K exists for conv_mfma_kernel only)
     a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
     a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
     a.NI = NI; a.H = H; a.W = W; a.up = up; a.res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;

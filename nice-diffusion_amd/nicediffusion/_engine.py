@@ -166,6 +166,14 @@ def _bf16_splitk():
     return int(os.environ.get('ND_BF16_SPLITK', '1'))
 
 
+def _f32_splitk():
+    """ND_F32_SPLITK (default 1): fp32 convolutions with few output pixels (<= 8192) and a long contraction are also measured
+    split over K (nd_conv_splitk_nhwc: 2 / 4 / 8 block rows over the input-channel chunks + a deterministic reduce) and run
+    that way where it is faster -- the 7x7 / 14x14 layers of the EMNIST preset at batch 4 run 16-64 blocks of a 1152-MFMA
+    serial chain otherwise; 0: never; 2: wherever the form exists (tests)."""
+    return int(os.environ.get('ND_F32_SPLITK', '1'))
+
+
 def _fuse_gn_mode():
     """0: never fold GroupNorm into the consumer conv; 1 (default): fold the affine-only norms (attention); 2: also fold
     norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
@@ -346,7 +354,16 @@ class UNetPlan:
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
         kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags, gn)
-        if kind == 'wino':
+        if kind == 'direct+splitk':
+            var, splits = var
+            need = self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, src.C + C1, ksize, splits)
+            if need <= 0:
+                raise _hip.NdHipError('nd_conv_splitk_workspace_floats: ' + _hip.last_error())
+            self._splitk_floats = max(self._splitk_floats, need)
+            wp = self._packed(weight, pad_c_to)
+            self._emit(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var, splits, ('splitk', 0)],
+                       label, flops=fl, variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+        elif kind == 'wino':
             wq = self._packed_wino(weight, pad_c_to)
             self.keep.append(wq)
             self.packed_floats += wq.numel()
@@ -635,11 +652,15 @@ class UNetPlan:
         ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
         NI, H, W, C, N, ksize, _, has_rb, _, _ = key
         heur = ('direct', self.lib.nd_conv_select_variant(NI, H, W, N, ksize, flags, 1 if has_rb else 0))
-        if not _autotune_enabled() or flops < 2e8:
+        # layers with few output pixels and a long contraction may run split over K: those are worth measuring from 2e7 flops
+        splitk_ok = _f32_splitk() and NI * H * W <= 8192 and C >= 128 and C % 32 == 0 and N % 4 == 0 and gn[0] is None and \
+            not (flags & _hip.CONV_RES_UP2X) and (pad_c_to is None or pad_c_to % 32 == 0)
+        if not _autotune_enabled() or flops < (2e7 if splitk_ok else 2e8):
             return heur
-        ck = (self.device.index,) + key
+        ck = (self.device.index,) + key + (('sk%d' % _f32_splitk(),) if splitk_ok else ())
         if ck in _TUNED:
-            return _TUNED[ck]
+            c = _TUNED[ck]
+            return (c[0], (c[1], c[2])) if c[0] == 'direct+splitk' else c
         stream = self._stream()
 
         def time_it(fn, args):
@@ -681,9 +702,20 @@ class UNetPlan:
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
             del wq
+        if splitk_ok:
+            splits = (2, 4, 8)
+            ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, ksize, S), 4) for S in splits),
+                             dtype=torch.float32, device=self.device)
+            cands = [7, 8, 6, 5] + ([best[1]] if best[0] == 'direct' and best[1] < 9 and best[1] not in (7, 8, 6, 5) else [])
+            for v in cands:
+                for S in splits:
+                    ms = time_it(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v, S, ws.data_ptr()])
+                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and best[0] != 'direct+splitk')):
+                        best, best_ms = ('direct+splitk', v, S), ms
+            del ws
         del wp
         _TUNED[ck] = best
-        return best
+        return (best[0], (best[1], best[2])) if best[0] == 'direct+splitk' else best
 
     def linear(self, src_ptr, M, K, weight, bias, out_ptr, N, flags=0, label='linear'):
         assert K % 4 == 0

@@ -824,6 +824,72 @@ def test_groupnorm_partial_rows_with_large_group_means(ratio):
     assert dy < max(bound, 2e-6) and (ratio > 10 or dy < 1e-4), (ratio, dy, bound)
 
 
+@pytest.mark.parametrize('B,C0,C1,N,H,W,ksize,opts', [
+    (4, 256, 0, 256, 7, 7, 3, 'bias'), (4, 256, 256, 256, 7, 7, 3, 'rowbias+res'), (3, 224, 160, 100, 7, 7, 3, 'res'),
+    (4, 128, 0, 128, 14, 14, 1, 'rowbias+res'), (2, 1024, 512, 768, 8, 8, 1, 'res'), (5, 128, 0, 64, 6, 10, 3, 'silu'),
+    (2, 96, 160, 192, 8, 8, 3, 'up2x+rowbias')])
+def test_conv_split_k_fp32(B, C0, C1, N, H, W, ksize, opts):
+    """nd_conv_splitk_nhwc (fp32): every conv_mfma_kernel tile variant x 2 / 4 / 8 splits over the input-channel chunks, with
+    the concatenation seam inside a split's range, N tails, per-image bias, residual, SiLU and the nearest-2x input read,
+    against F.conv2d; the partials are added in split order, so a launch is bitwise repeatable and differs from the one-pass
+    kernel only by the association of the K sum."""
+    up = 'up2x' in opts
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    xa = rnd(B, C0, Hs, Ws, seed=1)
+    xb = rnd(B, C1, Hs, Ws, seed=2) if C1 else None
+    x = torch.cat([xa, xb], 1) if C1 else xa
+    C = C0 + C1
+    w = rnd(N, C, ksize, ksize, seed=3, scale=0.05)
+    b = rnd(N, seed=4)
+    rb = rnd(B, N, seed=5) if 'rowbias' in opts else None
+    res = rnd(B, N, H, W, seed=6) if 'res' in opts else None
+    xin = F.interpolate(x, scale_factor=2.0, mode='nearest') if up else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=ksize // 2)
+    if rb is not None:
+        ref = ref + rb.double()[:, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    if 'silu' in opts:
+        ref = F.silu(ref)
+    ref = ref.float()
+    flags = (_hip.CONV_IN_UP2X if up else 0) | (_hip.CONV_SILU_OUT if 'silu' in opts else 0)
+    xad, xbd = nhwc(xa), (nhwc(xb) if C1 else None)
+    wd, bd = pack_w(w if ksize == 3 else w[:, :, 0, 0]), b.to(DEV)
+    rbd, resd = (rb.to(DEV) if rb is not None else None), (nhwc(res) if res is not None else None)
+    p = lambda t_: None if t_ is None else t_.data_ptr()
+    tail = [p(rbd), N if rb is not None else 0, p(resd), N if res is not None else 0]
+    one = torch.full((B * H * W * N,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail, one.data_ptr(), N,
+                                  B, H, W, N, ksize, flags, -1, None, None, 0, st()))
+    ran = 0
+    for S in (2, 4, 8):
+        need = lib().nd_conv_splitk_workspace_floats(B, H, W, N, C, ksize, S)
+        assert need > 0 and need % (B * H * W * N) == 0 and 2 <= need // (B * H * W * N) <= S
+        ws = torch.full((need,), float('nan'), device=DEV)
+        for v in range(9):
+            out = torch.full((B * H * W * N,), float('nan'), device=DEV)
+            rc = lib().nd_conv_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                           out.data_ptr(), N, B, H, W, N, ksize, flags, v, S, ws.data_ptr(), st())
+            if rc != 0:
+                assert any(m in _hip.last_error() for m in ('no tile variant fits', 'no 1x1 form')), (v, S, _hip.last_error())
+                continue
+            ran += 1
+            got = from_nhwc(out, B, H, W, N)
+            assert torch.isfinite(got).all(), (v, S)
+            err = (got - ref).abs().max().item()
+            assert err < 2e-4, (v, S, err)
+            assert (out - one).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (v, S)
+            out2 = torch.full_like(out, float('nan'))
+            _hip.check(lib().nd_conv_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                                 out2.data_ptr(), N, B, H, W, N, ksize, flags, v, S, ws.data_ptr(), st()))
+            assert torch.equal(out, out2), (v, S)
+    assert ran >= 12
+    # refused: stream / GEMM variants, a fused GroupNorm is not offered at all, too many splits for the chunks there are
+    assert lib().nd_conv_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail, one.data_ptr(), N,
+                                     B, H, W, N, ksize, flags, 11, 2, ws.data_ptr(), st()) != 0
+    assert lib().nd_conv_splitk_workspace_floats(B, H, W, N, 32, ksize, 2) < 0      # one chunk cannot be split
+
+
 @pytest.mark.parametrize('B,C,N,H,W', [(2, 32, 48, 16, 16), (3, 64, 64, 8, 12)])
 def test_stride2_conv_via_space_to_depth(B, C, N, H, W):
     """Downsample's stride-2 3x3 conv (model.py:103-108) = stride-1 3x3 conv of the space-to-depth tensor with the
