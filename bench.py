@@ -61,13 +61,16 @@ PER_GPU_BATCH = 64
 
 
 def synthetic_weights(model, seed=1234):
-    """Random weights of the architecture: N(0, 0.02) everywhere, N(0, 0.005) for the layers the reference
-    zero-initialises, GroupNorm weight 1 + 0.02 n (throughput does not depend on the values, but all-zero outputs
-    would let the chip clock higher than real data does)."""
-    g = torch.Generator().manual_seed(seed)
+    """SURVEY 8(d)'s synthetic weights: numpy.random.default_rng(1234) normals in state_dict key order, sigma 0.02 for
+    ordinary tensors, 0.005 for the tensors the reference zero-initialises (model.py:177,253,448), GroupNorm weight
+    1 + 0.02 n -- the same tensors tests/ build with the oracle's synth_state_dict(seed=1234), so the full-size parity tests
+    run the very model this file times.  (Throughput does not depend on the values, but all-zero outputs would let the chip
+    clock higher than real data does.)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
     with torch.no_grad():
-        for name, p in model.named_parameters():
-            n = torch.randn(p.shape, generator=g)
+        for name, p in model.state_dict().items():
+            n = torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32))
             if name.endswith('norm.weight') or name == 'out.0.weight':
                 p.copy_(1 + 0.02 * n)
             elif '.out_conv.' in name or '.proj_out.' in name or name.startswith('out.2.'):
@@ -117,7 +120,7 @@ def _traffic_table():
     """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/rNN_pmc_shapes.json:
     one entry per (kernel kind, variant, ksize, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
     inside this process, so the table is regenerated by that script and looked up by the shapes actually launched."""
-    for name in ('r03_pmc_shapes.json', 'r02_pmc_shapes.json'):
+    for name in ('r04_pmc_shapes.json', 'r03_pmc_shapes.json', 'r02_pmc_shapes.json'):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', name))), name
         except (OSError, ValueError):
@@ -292,6 +295,8 @@ def main():
     full_chain = wl['chain']
     if args.chain is None:
         args.chain = full_chain
+    if not 0 < args.chain <= full_chain:
+        raise SystemExit('--chain must be in 1..{} for {}'.format(full_chain, args.workload))
     if args.batch is None:
         args.batch = wl['batch']
 

@@ -222,6 +222,20 @@ def test_hand_scheduled_kernels_have_no_scratch_and_fit_two_waves_per_simd():
     assert seen == {'gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel'}, seen
 
 
+def test_bench_weights_are_the_survey_recipe_the_parity_tests_use():
+    """bench.py's synthetic weights (numpy default_rng(1234) in state_dict order, 0.02 / 0.005 / 1 + 0.02 n) are
+    bit for bit the oracle's synth_state_dict(seed=1234): the full-size GPU parity tests run the very model BENCH times."""
+    import bench
+    from nicediffusion import default_args as DA
+    from oracle import unet_oracle as UO
+    cfg = dict(DA.EMNIST_MODEL_ARGS)
+    m = DiffusionModel(**cfg)
+    bench.synthetic_weights(m)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    got = m.state_dict()
+    assert list(got) == list(sd) and all(torch.equal(sd[k], v) for k, v in got.items())
+
+
 # ------------------------------------------------------------------------------------------------- sharding
 def test_shard_slice_partitions():
     for n in (1, 7, 64, 512, 513):

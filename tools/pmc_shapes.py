@@ -18,14 +18,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
-            'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc')
-CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino16g_kernel', 'conv_wino16p_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel',
-                'gemm_stream_kernel', 'conv_bf16_kernel', 'conv_bf16w_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_bf16q_kernel', 'gemm_f32_kernel',
+            'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc',
+            'nd_conv_splitk_nhwc')
+CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel',
+                'gemm_stream_kernel', 'conv_bf16_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_bf16q_kernel', 'gemm_f32_kernel',
                 'gemm4_kernel')
 # the other kernel classes of a forward: counters aggregated per kernel name (no per-shape key)
 CLASS_KERNELS = ('attention_kernel', 'attention_bf16_kernel', 'gn_stats_kernel', 'gn_apply_kernel', 'gn_from_partials_kernel',
-                 'gn_coeffs_kernel', 'gn_coeffs_from_partials_kernel', 'splitk_reduce_kernel')
-OUT_NAME = os.environ.get('ND_PMC_OUT', 'r03_pmc_shapes.json')
+                 'gn_coeffs_kernel', 'gn_coeffs_from_partials_kernel', 'gn_fused_small_kernel', 'splitk_reduce_kernel', 'splitk_reduce_f32_kernel')
+OUT_NAME = os.environ.get('ND_PMC_OUT', os.environ.get('ROUND', 'r04') + '_pmc_shapes.json')
 
 
 def dispatches(d, kernels=CONV_KERNELS):
