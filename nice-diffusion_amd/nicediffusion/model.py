@@ -170,7 +170,11 @@ class DiffusionModel(nn.Module):
                                  zero_module(nn.Conv2d(first, out_channels, kernel_size=(3, 3), stride=(1, 1),
                                                        padding=(1, 1))))
         self._plans = {}
+        # Two host synchronisations per forward() / denoise() entry, each behind a switch for callers that want the call
+        # sync-free (e.g. to capture forward() into their own hipGraph): the digest of the weights against the cached
+        # plan's (verify_weights) and the range check of the labels (verify_labels)
         self.verify_weights = True     # digest the weights on the device before reusing a cached plan
+        self.verify_labels = True      # nn.Embedding raises on an out-of-range label (model.py:459): so does forward()
         # arithmetic of the forward: 'fp32' = the reference's (exact fp32 MFMA kernels); 'bf16' = bf16 activations and
         # weights with fp32 accumulation (parameters stay fp32; the cast happens in the plan's weight repack)
         self.compute_dtype = os.environ.get('ND_COMPUTE_DTYPE', 'fp32')      # e.g. ND_COMPUTE_DTYPE=bf16 scripts/sample.py ...
@@ -221,7 +225,7 @@ class DiffusionModel(nn.Module):
             digest = self._weight_digest() if self.verify_weights else None
             pkey = (batch, self.compute_dtype)
             plan = self._plans.get(pkey)
-            if plan is not None and (plan.weight_signature != sig or plan.weight_digest != digest):
+            if plan is not None and (plan.weight_signature != sig or (digest is not None and plan.weight_digest != digest)):
                 self.invalidate_plans()          # the other batch sizes' plans hold the same stale copies
                 plan = None
             if plan is None:

@@ -367,6 +367,33 @@ def test_variance_type_change_refreshes_coefficients_and_labels_are_validated():
         dc.denoise(x=torch.randn(1, 3, 16, 16), kwargs={'y': torch.tensor([-1])}, batch_size=1, progress=False)
 
 
+def test_forward_is_stream_capturable_by_the_caller():
+    """``DiffusionModel.forward`` makes two host synchronisations per call by default -- the digest of the weights against the
+    cached plan's (``verify_weights``) and the label range check (``verify_labels``).  With both switched off (a caller that
+    has validated its labels and does not edit weights behind the plan's back) the call is sync-free and allocation-safe,
+    so the CALLER can capture it into its own hipGraph and replay it on new inputs."""
+    m = build(TINY_CFGS['adagn_updown'])
+    x = torch.randn(2, 3, 16, 16, device=DEV)
+    t = torch.tensor([5, 700], device=DEV)
+    y = torch.tensor([1, 2], device=DEV)
+    ref = m(x, t, y).clone()                          # builds the plan, warms lazy kernel attributes
+    m.verify_weights = False
+    m.verify_labels = False
+    m(x, t, y)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(x, t, y)
+    g.replay()
+    assert torch.equal(out, ref)
+    x2 = torch.randn(2, 3, 16, 16, device=DEV)
+    x.copy_(x2)
+    t.copy_(torch.tensor([900, 3], device=DEV))
+    g.replay()
+    m.verify_weights = m.verify_labels = True
+    assert torch.equal(out, m(x2, torch.tensor([900, 3], device=DEV), y))
+
+
 def test_one_captured_graph_serves_every_seed():
     """The Philox key lives in a device word, so DDPM sampling with a fresh seed per call reuses the captured graph."""
     m = build(TINY_CFGS['adagn_updown'])

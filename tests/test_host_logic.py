@@ -236,6 +236,37 @@ def test_bench_weights_are_the_survey_recipe_the_parity_tests_use():
     assert list(got) == list(sd) and all(torch.equal(sd[k], v) for k, v in got.items())
 
 
+def test_committed_tune_caches_match_the_built_library():
+    """profiles/tune_cache_<workload>.json (the kernel choices bench.py and the full-size tests build their plans from) carry
+    the stamp of THIS library build -- version + variant tables -- so a kernel change that forgot to regenerate them is
+    flagged here instead of silently falling back to tuning on the box; every choice names an existing variant."""
+    from nicediffusion import _engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _hip.load()
+    for wl in ('config1', 'config2', 'config4', 'config5'):
+        path = os.path.join(root, 'profiles', 'tune_cache_{}.json'.format(wl))
+        raw = json.load(open(path))
+        assert raw.pop('__stamp__') == _engine._tune_stamp(), wl
+        assert len(raw) >= 20, (wl, len(raw))
+        for k, v in raw.items():
+            kind, var = v[0], v[1]
+            if kind.startswith('bf16'):
+                assert 0 <= var < lib.nd_conv_bf16_num_variants() and not lib.nd_conv_bf16_variant_name(var).startswith(b'(retired)')
+            elif kind == 'wino':
+                assert 0 <= var < lib.nd_conv_winograd_num_variants() and \
+                    not lib.nd_conv_winograd_variant_name(var).startswith(b'(retired)')
+            else:
+                assert kind in ('direct', 'direct+splitk') and 0 <= var < lib.nd_conv_num_variants(), (k, v)
+        saved = dict(_engine._TUNED)
+        try:
+            _engine._TUNED.clear()
+            assert _engine.preload_tune_cache(path, device_index=5) == len(raw)
+            assert all(key[0] == 5 for key in _engine._TUNED)
+        finally:
+            _engine._TUNED.clear()
+            _engine._TUNED.update(saved)
+
+
 # ------------------------------------------------------------------------------------------------- sharding
 def test_shard_slice_partitions():
     for n in (1, 7, 64, 512, 513):
