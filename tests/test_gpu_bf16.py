@@ -908,7 +908,7 @@ def test_full_size_properties_bf16(golden_dir, pname, B, cfg):
     ref_rows = full_batch_forward(m, R, B, cfg, int(g['t'][0]))[torch.from_numpy(g['rows'])].cpu().numpy()
     rms0, mx0 = _errs(ref_rows[:, :, ::gst, ::gst], g['out_sub'])
     print(pname, 'bf16 full-batch rows vs the fp32 reference: rel rms {:.3e}, max/absmax {:.3e}'.format(rms0, mx0))
-    assert rms0 < 2.1e-2 and mx0 < 5e-2, (rms0, mx0)
+    assert rms0 < 1.9e-2 and mx0 < 2.3e-2, (rms0, mx0)         # measured 9.6e-3 / 1.14e-2 (128x128), 8.9e-3 / 9.5e-3 (256x256)
     torch.manual_seed(0)
     x = torch.randn(NI, 3, R, R)
     y = (torch.arange(NI) * 37) % 1000 + 1
