@@ -228,7 +228,7 @@ def class_breakdown(rows):
 def cpu_baseline(model, margs, wl, batch=None, steps=2):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned against it in tests/) on this box's
     host cores.  configs[0] runs IN FULL (the whole 50-step chain at batch 4, 3 repeats, median).  The other workloads
-    take a bounded sample (BASELINE.md section 4 / SURVEY 8(d)) -- one untimed + 2 timed sampler steps (UNet forward(s) +
+    take a bounded sample (BASELINE.md section 4 / SURVEY 8(d)) -- a batch-2 warm-up + 2 timed sampler steps (UNet forward(s) +
     update) at batch 16 / 4 / 2 for the 64 / 128 / 256-pixel presets, where the host's threads are better used than at
     batch 4 -- extrapolated to the whole chain; it is a reported baseline, not a target."""
     from oracle import unet_oracle as UO, diffusion_oracle as DO
@@ -261,15 +261,18 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
     y = (torch.arange(batch) * 37) % ncls + (1 if wl['cfg'] is not None else 0)
     step = so.ddim_step if wl['ddim'] else so.ddpm_step
     t = wl['chain'] - 1
-    x, _ = step(x, t, y)          # warm-up (thread pool, oneDNN primitive cache)
-    t0 = time.perf_counter()
+    step(x[:2], t, y[:2])         # warm-up at batch 2 (thread pool, allocator; the timed steps are the first at this batch)
+    ts = []
     for i in range(steps):
-        x, _ = step(x, t - 1 - i, y)
-    dt = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        x, _ = step(x, t - i, y)
+        ts.append(time.perf_counter() - t0)
+    dt = sum(ts) / steps
     nfwd = batch * (2 if wl['cfg'] is not None else 1)
     return {'value': round(batch / (dt * wl['chain']), 6), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port', 'host_cpus': os.cpu_count(), 's_per_image_forward': round(dt / nfwd, 4),
-            'sample': '{} timed sampler step{} (UNet forward{} + update; one more untimed before) at batch {} of the same {}x{} '
+            'step_s': [round(v, 2) for v in ts],
+            'sample': '{} timed sampler step{} (UNet forward{} + update; a batch-2 step untimed before) at batch {} of the same {}x{} '
                       'preset on {} threads of the host, {:.2f} s/step = {:.3f} s per image-forward, extrapolated x{} steps'.format(
                           steps, '' if steps == 1 else 's', 's (2 per step, CFG)' if wl['cfg'] is not None else '', batch, R, R,
                           torch.get_num_threads(), dt, dt / nfwd, wl['chain'])}

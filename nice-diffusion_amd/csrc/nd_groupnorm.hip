@@ -326,25 +326,59 @@ __global__ void __launch_bounds__(GN_NT)
 // twice: float64 sums in a fixed order (thread-strided items, then a fixed LDS tree: bitwise repeatable, no atomics),
 // the group's coefficients y = x * A[c] + B[c] in LDS with gn_apply_kernel's arithmetic, then the second pass writes the
 // normalised (+AdaGN, +SiLU, +2x2 average pool) tensor.  Replaces channel-partials + fold + apply (3 launches of ~6 us).
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool VEC>
 __global__ void __launch_bounds__(256)
     gn_fused_small_kernel(GnSrc<T> s, const float* gamma, const float* beta, const float* scale, const float* shift, int ld_ss,
                           T* out, int ldo, int H, int W, int G, float eps, int silu) {
+    // VEC: the group's channels are whole 16-byte vectors in both sources (C / G, C0, the strides multiples of 4 fp32 / 8
+    // bf16 channels, pointers aligned): an item is one vector of one pixel; otherwise one channel of one pixel
+    constexpr int V = VEC ? GnVec<T>::N : 1;
     __shared__ double red[2][256];
     __shared__ float cA[64], cB[64];                  // C / G <= GN_MAXCH / 32
     const int g = blockIdx.x, img = blockIdx.y, t = threadIdx.x;
     const int C = s.C0 + s.C1;
     const int cpg = C / G;
+    const int q = cpg / V;                            // items per pixel
     const int c_lo = g * cpg;
     const int HW = H * W;
-    const int n = HW * cpg;
+    const int n = HW * q;
     const size_t ibase = (size_t)img * HW;
+    auto load = [&](size_t pix, int c, float (&v)[V]) {
+        if constexpr (VEC) GnVec<T>::load(gn_ptr(s, pix, c), v);
+        else v[0] = (float)*gn_ptr(s, pix, c);
+    };
     double a = 0.0, b = 0.0;
-    for (int i = t; i < n; i += 256) {
-        const int pix = i / cpg, c = c_lo + (i - pix * cpg);
-        const double v = (double)(float)*gn_ptr(s, ibase + pix, c);
-        a += v;
-        b += v * v;
+    {
+        // four items in flight per thread (the pass is latency-bound: a block owns a few KB)
+        int i = t;
+        for (; i + 3 * 256 < n; i += 4 * 256) {
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + u * 256;
+                const int pix = ii / q;
+                load(ibase + pix, c_lo + (ii - pix * q) * V, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const double d = (double)v[u][e];
+                    a += d;
+                    b += d * d;
+                }
+        }
+        for (; i < n; i += 256) {
+            float v[V];
+            const int pix = i / q;
+            load(ibase + pix, c_lo + (i - pix * q) * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const double d = (double)v[e];
+                a += d;
+                b += d * d;
+            }
+        }
     }
     red[0][t] = a;
     red[1][t] = b;
@@ -357,7 +391,7 @@ __global__ void __launch_bounds__(256)
         __syncthreads();
     }
     if (t < cpg) {
-        const double inv_n = 1.0 / (double)n;
+        const double inv_n = 1.0 / ((double)HW * (double)cpg);
         const double mean = red[0][0] * inv_n;
         double var = red[1][0] * inv_n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -376,26 +410,39 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     const int Wo = POOL ? (W >> 1) : W, HWo = POOL ? (H >> 1) * Wo : HW;
     const size_t obase = (size_t)img * HWo;
-    const int no = HWo * cpg;
+    const int no = HWo * q;
     for (int i = t; i < no; i += 256) {
-        const int po = i / cpg, cc = i - po * cpg, c = c_lo + cc;
-        const float ka = cA[cc], kb = cB[cc];
-        float y;
+        const int po = i / q, cc = (i - po * q) * V, c = c_lo + cc;
+        float y[V];
         if (POOL) {
             const int oy = po / Wo, ox = po - oy * Wo;
-            y = 0.f;
+            float v[4][V];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v = (float)*gn_ptr(s, ibase + (size_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1), c) * ka + kb;
-                if (silu) v = fast_silu(v);
-                y += v;
+            for (int k = 0; k < 4; ++k) load(ibase + (size_t)(2 * oy + (k >> 1)) * W + 2 * ox + (k & 1), c, v[k]);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float ka = cA[cc + e], kb = cB[cc + e];
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float z = v[k][e] * ka + kb;
+                    if (silu) z = fast_silu(z);
+                    acc += z;
+                }
+                y[e] = acc * 0.25f;
             }
-            y *= 0.25f;
         } else {
-            y = (float)*gn_ptr(s, ibase + po, c) * ka + kb;
-            if (silu) y = fast_silu(y);
+            float v[V];
+            load(ibase + po, c, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float z = v[e] * cA[cc + e] + cB[cc + e];
+                if (silu) z = fast_silu(z);
+                y[e] = z;
+            }
         }
-        out[(obase + po) * ldo + c] = (T)y;
+        if constexpr (VEC) GnVec<T>::store(out + (obase + po) * ldo + c, y);
+        else out[(obase + po) * ldo + c] = (T)y[0];
     }
 }
 
@@ -738,14 +785,22 @@ extern "C" int nd_groupnorm_fused_nhwc(const void* x0, int C0, int ldx0, const v
     const int silu = (flags & ND_GN_SILU) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(G, NI), blk(256);
+    const int vq = dtype == ND_DT_BF16 ? 8 : 4;
+    const int cpg = (C0 + C1) / G;
+    const bool vec = (cpg % vq) == 0 && (C0 % vq) == 0 && (ldx0 % vq) == 0 && (C1 == 0 || (ldx1 % vq) == 0) && (ldo % vq) == 0 &&
+                     aligned16(x0) && (C1 == 0 || aligned16(x1)) && aligned16(out);
+#define ND_GNF_LAUNCH(TY, POOLV, VECV)                                                                                             \
+    hipLaunchKernelGGL((gn_fused_small_kernel<TY, POOLV, VECV>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss,             \
+                       static_cast<TY*>(out), ldo, H, W, G, eps, silu)
     if (dtype == ND_DT_BF16) {
         GnSrc<__bf16> s{static_cast<const __bf16*>(x0), static_cast<const __bf16*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
-        if (pool) hipLaunchKernelGGL((gn_fused_small_kernel<__bf16, true>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<__bf16*>(out), ldo, H, W, G, eps, silu);
-        else hipLaunchKernelGGL((gn_fused_small_kernel<__bf16, false>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<__bf16*>(out), ldo, H, W, G, eps, silu);
+        if (pool) { if (vec) ND_GNF_LAUNCH(__bf16, true, true); else ND_GNF_LAUNCH(__bf16, true, false); }
+        else { if (vec) ND_GNF_LAUNCH(__bf16, false, true); else ND_GNF_LAUNCH(__bf16, false, false); }
     } else {
         GnSrc<float> s{static_cast<const float*>(x0), static_cast<const float*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
-        if (pool) hipLaunchKernelGGL((gn_fused_small_kernel<float, true>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<float*>(out), ldo, H, W, G, eps, silu);
-        else hipLaunchKernelGGL((gn_fused_small_kernel<float, false>), grid, blk, 0, st, s, gamma, beta, scale, shift, ld_ss, static_cast<float*>(out), ldo, H, W, G, eps, silu);
+        if (pool) { if (vec) ND_GNF_LAUNCH(float, true, true); else ND_GNF_LAUNCH(float, true, false); }
+        else { if (vec) ND_GNF_LAUNCH(float, false, true); else ND_GNF_LAUNCH(float, false, false); }
     }
+#undef ND_GNF_LAUNCH
     return check_launch(fn);
 }

@@ -151,12 +151,14 @@ def _bf16_epilogue_stats():
     return int(os.environ.get('ND_BF16_EPILOGUE_STATS', '1'))
 
 
-def _gn_fused_max_elems():
-    """ND_GN_FUSED_MAX (default 2^20 elements = 4 MB of fp32): a GroupNorm over at most that many elements (images x pixels
-    x channels) takes ONE launch (nd_groupnorm_fused_nhwc: statistics + apply, one block per (group, image)) instead of
-    the per-channel partials pass, the fold and the apply pass.  Such plans are launch-bound (the EMNIST preset at batch
-    4: 257 -> 149 launches per forward); 0 switches the form off."""
-    return int(os.environ.get('ND_GN_FUSED_MAX', str(1 << 20)))
+def _gn_fused_max_elems(bf16=False):
+    """ND_GN_FUSED_MAX (default 2^23 elements in fp32 plans, 2^22 in bf16 plans): a GroupNorm over at most that many elements
+    (images x pixels x channels) takes ONE launch (nd_groupnorm_fused_nhwc: statistics + apply, one block per (group,
+    image), 16-byte loads) instead of the per-channel partials pass, the fold and the apply pass.  Measured (interleaved,
+    same box): the EMNIST preset at batch 4 is launch-bound (257 -> 149 launches per forward); on
+    configs[1] the 8x8 level's norms (3.1 / 6.3 M elements, three launches of 6-11 us each) gain 0.2 ms per forward at 2^23
+    and the 16x16 level (9.4 M) loses 0.6 ms at 2^24; configs[3] / [4] gain 1.2 % / 0.55 % at 2^22.  0 switches the form off."""
+    return int(os.environ.get('ND_GN_FUSED_MAX', str(1 << 22 if bf16 else 1 << 23)))
 
 
 def _bf16_splitk():
@@ -734,7 +736,7 @@ class UNetPlan:
         C = src.C + (0 if src2 is None else src2.C)
         NI, H, W = src.NI, src.H, src.W
         s2 = (None, 0, 0) if src2 is None else (src2.ptr, src2.C, src2.ld)
-        if NI * H * W * C <= _gn_fused_max_elems() and C // GN_GROUPS <= 64 and (not pool or (H % 2 == 0 and W % 2 == 0)):
+        if NI * H * W * C <= _gn_fused_max_elems(self.bf16) and C // GN_GROUPS <= 64 and (not pool or (H % 2 == 0 and W % 2 == 0)):
             # small tensor: statistics and apply in one launch; the normalised tensor is materialised
             out = self._new(NI, H // 2 if pool else H, W // 2 if pool else W, C)
             flags = (_hip.GN_SILU if silu else 0) | (_hip.GN_POOL2 if pool else 0)
