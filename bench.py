@@ -225,12 +225,30 @@ def class_breakdown(rows):
     return {k: round(v, 3) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
 
 
+def pick_cpu_threads(fn):
+    """PyTorch's default thread count (the box's physical cores) is not the fastest for these small convolutions on a
+    two-socket host: run ``fn`` (one small sampler step; also the warm-up of the thread pool and allocator) at the default
+    and at 1/2, 1/4, 1/8 of it, leave the fastest count set and return (it, the default, {count: seconds})."""
+    default_threads = torch.get_num_threads()
+    tried = {}
+    fn()
+    for th in sorted({default_threads, max(8, default_threads // 2), max(8, default_threads // 4), max(8, default_threads // 8)},
+                     reverse=True):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        fn()
+        tried[th] = round(time.perf_counter() - t0, 2)
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    return best, default_threads, tried
+
+
 def cpu_baseline(model, margs, wl, batch=None, steps=2):
     """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned against it in tests/) on this box's
     host cores.  configs[0] runs IN FULL (the whole 50-step chain at batch 4, 3 repeats, median).  The other workloads
-    take a bounded sample (BASELINE.md section 4 / SURVEY 8(d)) -- small warm-up steps that also pick the thread count, then 2
-    timed sampler steps (UNet forward(s) + update) at batch 16 / 4 / 2 for the 64 / 128 / 256-pixel presets, where the host's threads are better used than at
-    batch 4 -- extrapolated to the whole chain; it is a reported baseline, not a target."""
+    take a bounded sample (BASELINE.md section 4 / SURVEY 8(d)) -- 2 timed sampler steps (UNet forward(s) + update) at batch
+    16 / 4 / 2 for the 64 / 128 / 256-pixel presets -- extrapolated to the whole chain.  Both run at the fastest of four
+    thread counts (pick_cpu_threads); it is a reported baseline, not a target."""
     from oracle import unet_oracle as UO, diffusion_oracle as DO
     R = margs['resolution']
     ncls = wl.get('classes', 1000)
@@ -243,17 +261,18 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
         torch.manual_seed(0)
         x = torch.randn(B, margs.get('in_channels', 1), R, R)
         y = (torch.arange(B) * 37) % ncls
-        so.denoise(x, y)                              # warm-up (thread pool, oneDNN primitive cache)
+        best_threads, default_threads, tried = pick_cpu_threads(lambda: so.ddim_step(x, wl['chain'] - 1, y))
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
             so.denoise(x, y)
             ts.append(time.perf_counter() - t0)
+        torch.set_num_threads(default_threads)
         med = sorted(ts)[1]
-        return {'value': round(B / med, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-                'host_cpus': os.cpu_count(), 'runs_s': [round(t, 3) for t in ts],
-                'sample': 'the whole workload: {}-step DDIM chain at batch {} on the host cores, 3 repeats, median {:.2f} s'
-                          .format(wl['chain'], B, med)}
+        return {'value': round(B / med, 4), 'unit': 'images/sec', 'cores': best_threads, 'kind': 'port',
+                'host_cpus': os.cpu_count(), 'runs_s': [round(t, 3) for t in ts], 'threads_tried_s_per_step': tried,
+                'sample': 'the whole workload: {}-step DDIM chain at batch {} on {} threads of the host (the fastest of {}), 3 '
+                          'repeats, median {:.2f} s'.format(wl['chain'], B, best_threads, sorted(tried), med)}
     if batch is None:
         batch = 16 if R <= 64 else (4 if R <= 128 else 2)
     torch.manual_seed(0)
@@ -261,21 +280,8 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
     y = (torch.arange(batch) * 37) % ncls + (1 if wl['cfg'] is not None else 0)
     step = so.ddim_step if wl['ddim'] else so.ddpm_step
     t = wl['chain'] - 1
-    # PyTorch's default thread count (the box's physical cores) is not the fastest for these convolutions on a two-socket
-    # host: one small step (also the warm-up of the thread pool and allocator) at the default and at 1/2, 1/4, 1/8 of it, and
-    # the timed steps run at the best of them -- the stated baseline is the box's best, not its default
-    default_threads = torch.get_num_threads()
     nb = min(4, batch)
-    tried = {}
-    step(x[:nb], t, y[:nb])
-    for th in sorted({default_threads, max(8, default_threads // 2), max(8, default_threads // 4), max(8, default_threads // 8)},
-                     reverse=True):
-        torch.set_num_threads(th)
-        t0 = time.perf_counter()
-        step(x[:nb], t, y[:nb])
-        tried[th] = round(time.perf_counter() - t0, 2)
-    best_threads = min(tried, key=tried.get)
-    torch.set_num_threads(best_threads)
+    best_threads, default_threads, tried = pick_cpu_threads(lambda: step(x[:nb], t, y[:nb]))
     ts = []
     for i in range(steps):
         t0 = time.perf_counter()
@@ -287,7 +293,8 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
     return {'value': round(batch / (dt * wl['chain']), 6), 'unit': 'images/sec', 'cores': best_threads,
             'kind': 'port', 'host_cpus': os.cpu_count(), 's_per_image_forward': round(dt / nfwd, 4),
             'step_s': [round(v, 2) for v in ts], 'threads_tried_s_per_batch{}_step'.format(nb): tried,
-            'sample': '{} timed sampler step{} (UNet forward{} + update; small untimed steps before, which also pick the thread count) at batch {} of the same {}x{} '
+            'sample': '{} timed sampler step{} (UNet forward{} + update; small untimed steps before, which also pick the thread '
+                      'count) at batch {} of the same {}x{} '
                       'preset on {} threads of the host, {:.2f} s/step = {:.3f} s per image-forward, extrapolated x{} steps'.format(
                           steps, '' if steps == 1 else 's', 's (2 per step, CFG)' if wl['cfg'] is not None else '', batch, R, R,
                           best_threads, dt, dt / nfwd, wl['chain'])}
