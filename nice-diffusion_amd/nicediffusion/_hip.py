@@ -124,6 +124,11 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch first: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so) and every device pointer this library
+    # is handed comes from THAT runtime.  Loaded after torch, libnd_hip.so binds to the runtime already in the process;
+    # loaded before it (python __graft_entry__.py smoke: build() then smoke() in one process), the system's
+    # /opt/rocm/lib/libamdhip64.so.7 comes in first and the first call on a torch pointer fails (hipMemsetAsync: invalid)
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise NdHipError('libnd_hip.so not found at {} -- build it with `make -C nice-diffusion_amd` '
                          '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no CPU fallback'

@@ -34,6 +34,17 @@ def test_native_library_is_the_one_loaded():
     assert lib.nd_device_arch().decode().startswith('gfx950')
 
 
+def test_build_then_smoke_in_one_fresh_process():
+    """``python __graft_entry__.py smoke`` = build() then smoke() in ONE process: build() loads libnd_hip.so before anything
+    has touched torch.  The library must still end up on the HIP runtime torch uses (``_hip.load`` imports torch first);
+    loaded the other way round, the system's runtime came in first and the first call on a torch pointer failed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, '__graft_entry__.py'), 'smoke'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'smoke ok' in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize('name', sorted(TINY_CFGS))
 def test_tiny_forward_vs_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, 'fwd_{}.npz'.format(name)))
