@@ -105,6 +105,13 @@ int nd_conv_splitk_nhwc(const float* x0, int C0, int ldx0, const float* x1, int 
                         const float* residual, int ldr, float* out, int ldo,
                         int NI, int H, int W, int N, int ksize, int flags, int variant, int splits,
                         float* workspace, nd_stream_t stream);
+/* The Winograd form split over K (conv_wino4_kernel, variant 12, only): 3x3 layers on small maps at large batch whose
+ * output tiles do not fill the chip evenly; same scheme, restrictions and workspace (ksize 3) as nd_conv_splitk_nhwc. */
+int nd_conv3x3_winograd_splitk_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                    const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                    const float* residual, int ldr, float* out, int ldo,
+                                    int NI, int H, int W, int N, int flags, int variant, int splits,
+                                    float* workspace, nd_stream_t stream);
 int64_t nd_conv_splitk_workspace_floats(int NI, int H, int W, int N, int C, int ksize, int splits);
 int nd_conv_select_variant(int NI, int H, int W, int N, int ksize, int flags, int has_rowbias);
 int nd_conv_variant_info(int variant, int* bm, int* bn, int* threads);

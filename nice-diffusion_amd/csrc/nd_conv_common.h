@@ -134,6 +134,20 @@ __host__ __device__ inline int nc32_padded(int C) {
     return (c + 1) & ~1;      // even number of 32-channel chunks (the 1x1 kernel walks two per barrier)
 }
 
+// the split plan shared by nd_conv_splitk_nhwc, nd_conv3x3_winograd_splitk_nhwc and nd_conv_splitk_workspace_floats: whole
+// LDS chunks per split (32 channels for 3x3, pairs of them for 1x1); returns the number of splits actually used (< 2:
+// cannot split) and the chunks per split
+static inline int splitk_plan_f32(int C, int ksize, int splits, int* kchunks) {
+    const int nc32 = (C + 31) / 32, unit = ksize == 3 ? 1 : 2;
+    int kc = (nc32 + splits - 1) / splits;
+    kc = (kc + unit - 1) / unit * unit;
+    *kchunks = kc;
+    return (nc32 + kc - 1) / kc;
+}
+// second pass of a split launch (nd_conv_mfma.hip): out = sum_s ws[s] + bias + rowbias[img] + residual, SiLU last
+int launch_splitk_reduce_f32(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
+                             int ld_rowbias, int hw, const float* res, int ldr, float* out, int ldo, int silu, hipStream_t s);
+
 struct TilePlan {
     int thl, twl, nibl, tiles_x, tiles_y, groups, hp;
     long padded;   // padded pixel count

@@ -431,6 +431,16 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+int launch_splitk_reduce_f32(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
+                             int ld_rowbias, int hw, const float* res, int ldr, float* out, int ldo, int silu, hipStream_t s) {
+    const long quads = M * (N >> 2);
+    long rg = (quads + 255) / 256;
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((int)rg), dim3(256), 0, s, ws, S, ws_stride, M, N, bias, rowbias, ld_rowbias, hw,
+                       res, ldr, out, ldo, silu);
+    return check_launch("split-K reduce");
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 1x1 "stream" form (flat pixel list only): a 1x1 convolution is a plain GEMM, and with K = Cin of a few hundred a
 // block lives for ~12 chunks -- too short to amortise the LDS staging + barrier per chunk of the kernel above.  Here
@@ -818,16 +828,6 @@ extern "C" int nd_repack_conv_weight(const float* w, float* w_out, int N, int C,
     return check_launch(fn);
 }
 
-// the split plan shared by conv_f32_impl and nd_conv_splitk_workspace_floats: whole LDS chunks per split (32 channels for
-// 3x3, pairs of them for 1x1); returns the number of splits actually used (< 2: cannot split) and the chunks per split
-static int splitk_plan_f32(int C, int ksize, int splits, int* kchunks) {
-    const int nc32 = (C + 31) / 32, unit = ksize == 3 ? 1 : 2;
-    int kc = (nc32 + splits - 1) / splits;
-    kc = (kc + unit - 1) / unit * unit;
-    *kchunks = kc;
-    return (nc32 + kc - 1) / kc;
-}
-
 static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                          const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                          const float* residual, int ldr, float* out, int ldo,
@@ -941,12 +941,8 @@ static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, cons
     }
     const int rc = (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
     if (rc != ND_OK || a.ksplit <= 1) return rc;
-    const long quads = M * (N >> 2);
-    long rg = (quads + 255) / 256;
-    if (rg > 4096) rg = 4096;
-    hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((int)rg), dim3(256), 0, s, workspace, a.ksplit, a.ws_stride, M, N, bias, rowbias,
-                       ld_rowbias, H * W, residual, ldr, out, ldo, (flags & ND_CONV_SILU_OUT) ? 1 : 0);
-    return check_launch(fn);
+    return launch_splitk_reduce_f32(workspace, a.ksplit, a.ws_stride, M, N, bias, rowbias, ld_rowbias, H * W, residual, ldr, out, ldo,
+                                    (flags & ND_CONV_SILU_OUT) ? 1 : 0, s);
 }
 
 extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,

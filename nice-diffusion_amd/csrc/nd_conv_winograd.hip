@@ -890,7 +890,8 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
                        const float* w, const float* bias, const float* rowbias, int ld_rowbias,
                        const float* residual, int ldr, float* out, int ldo,
                        int NI, int H, int W, int N, int flags, int variant,
-                       const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream) {
+                       const float* gnA, const float* gnB, int ld_gn, float* chstats, nd_stream_t stream, int splits = 1,
+                       float* workspace = nullptr) {
     const char* fn = "nd_conv3x3_winograd_nhwc";
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -919,7 +920,21 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
     if (!found) return fail_arg(fn, "no tiling fits this shape");
     const int up = (flags & ND_CONV_IN_UP2X) ? 1 : 0;
     ConvArgs a;
-    a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;      // (split-K exists for conv_mfma_kernel only)
+    a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;
+    if (splits > 1) {
+        // conv_wino4_kernel only: block row s runs the 32-channel chunks of split s and leaves raw accumulators in the
+        // workspace; splitk_reduce_f32_kernel adds them in split order with bias / per-image bias / residual / SiLU
+        ND_REQUIRE(quad && workspace != nullptr && aligned16(workspace) && chstats == nullptr && gnA == nullptr, fn,
+                   "split-K: conv_wino4_kernel (variant 12) only, a 16-byte aligned workspace, no output statistics, no fused GroupNorm");
+        ND_REQUIRE(!(flags & ND_CONV_RES_UP2X) && (N & 3) == 0 && (ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                   (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
+                   (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias))), fn,
+                   "split-K: N and the strides must be multiples of 4 with 16-byte aligned pointers; no 2x-upsampled residual");
+        int kc = 0;
+        const int S = splitk_plan_f32(C0 + C1, 3, splits, &kc);
+        ND_REQUIRE(S > 1, fn, "split-K: too few input channels for that many splits");
+        a.ksplit = S; a.kchunks = kc; a.ws_stride = (long)NI * H * W * N;
+    }
     a.x0 = x0; a.x1 = (C1 > 0) ? x1 : x0; a.w = w; a.bias = bias; a.rowbias = rowbias; a.res = residual; a.out = out;
     a.C0 = C0; a.C1 = C1; a.ldx0 = ldx0; a.ldx1 = (C1 > 0) ? ldx1 : ldx0;
     a.NI = NI; a.H = H; a.W = W; a.up = up; a.res_up = (flags & ND_CONV_RES_UP2X) ? 1 : 0;
@@ -969,6 +984,10 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         ND_REQUIRE((a.NC32 & 1) == 0, fn, "the persistent form needs an even number of 32-channel chunks");
         lds = (size_t)best.hp * 128 + (size_t)128 * 1024;      // halo buffer 0 | exchange buffers (over halo buffer 1)
     }
+    if (a.ksplit > 1) {
+        a.bias = nullptr; a.rowbias = nullptr; a.res = nullptr; a.out = workspace; a.ldo = N; a.silu_out = 0; a.res_up = 0;
+        a.vec_ok = 1;                    // N % 4 == 0 and the workspace is 16-byte aligned
+    }
     a.zero = w + (nd_conv_winograd_weight_floats(N, C0 + C1) - 256);     // inside the zero padding block
     a.chstats = chstats;
     a.mbi = (best.nibl == 0) ? best.tiles_x * best.tiles_y : 1;
@@ -984,7 +1003,12 @@ static int wino_launch(const float* x0, int C0, int ldx0, const float* x1, int C
         case 6: return launch_wino<1, 2, false, 3>(a, grid, lds, s);
         case 7: return launch_wino<1, 1, false, 3>(a, grid, lds, s);
         case 8: return launch_wino16<1>(a, grid, lds, s);
-        case 12: return launch_wino4(a, grid, lds, s);
+        case 12: {
+            const int rc = launch_wino4(a, grid, lds, s);
+            if (rc != ND_OK || a.ksplit <= 1) return rc;
+            return launch_splitk_reduce_f32(workspace, a.ksplit, a.ws_stride, (long)NI * H * W, N, bias, rowbias, ld_rowbias, H * W,
+                                            residual, ldr, out, ldo, (flags & ND_CONV_SILU_OUT) ? 1 : 0, s);
+        }
     }
     return fail_arg(fn, "bad variant");
 }
@@ -996,6 +1020,19 @@ extern "C" int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const
                                         const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
                        flags, variant, gnA, gnB, ld_gn, nullptr, stream);
+}
+
+// The same convolution split over K by conv_wino4_kernel (variant 12): for 3x3 layers on small maps at large batch whose
+// output tiles do not fill the chip evenly (8x8 x 768 channels at 64 images: 384 blocks for 512 slots); see
+// nd_conv_splitk_nhwc for the scheme and nd_conv_splitk_workspace_floats(NI, H, W, N, C, 3, splits) for the workspace.
+extern "C" int nd_conv3x3_winograd_splitk_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                               const float* w, const float* bias, const float* rowbias, int ld_rowbias,
+                                               const float* residual, int ldr, float* out, int ldo,
+                                               int NI, int H, int W, int N, int flags, int variant, int splits,
+                                               float* workspace, nd_stream_t stream) {
+    if (splits < 2 || splits > 16 || !workspace) return fail_arg("nd_conv3x3_winograd_splitk_nhwc", "2..16 splits and a workspace");
+    return wino_launch(x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W, N,
+                       flags, variant, nullptr, nullptr, 0, nullptr, stream, splits, workspace);
 }
 
 extern "C" int nd_conv_winograd_stats_variant(void) { return kStatsVariant; }

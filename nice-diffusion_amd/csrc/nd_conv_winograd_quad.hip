@@ -64,7 +64,11 @@ __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
 
 template <bool STATS>          // STATS: also leave the per-channel partial statistics of the output behind (p.chstats)
 __global__ void __launch_bounds__(256, 2)
-    conv_wino4_kernel(const ConvArgs p) {
+    conv_wino4_kernel(const ConvArgs pin) {
+    ConvArgs p = pin;
+    // split over K (nd_conv3x3_winograd_splitk_nhwc): block row s runs the 32-channel chunks of split s; the transformed
+    // weights are chunk-major ([c32][n tile][kc][position 16][lane][4]), i.e. 16 "taps" of 4 k-steps per chunk and n tile
+    if (!STATS && pin.ksplit > 1) split_k_args_f32(p, blockIdx.y, 16);
     constexpr int BN = 64;
     constexpr int FRAGS = 64;
     constexpr int NDMA = kWino4HaloRounds;     // halo DMA rounds per chunk: 7 x 4 waves x 64 lanes x 16 B = 28 KiB >= 208 px x 128 B
@@ -619,7 +623,7 @@ int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
     } else {
         static bool attr_set[kMaxDevices] = {};
         if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wino4_kernel<false>), attr_set, "nd_conv3x3_winograd_nhwc")) return rc;
-        hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv_wino4_kernel<false>, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
     }
     return check_launch("nd_conv3x3_winograd_nhwc");
 }

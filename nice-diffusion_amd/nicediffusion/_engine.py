@@ -356,7 +356,18 @@ class UNetPlan:
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
         kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags, gn)
-        if kind == 'direct+splitk':
+        if kind == 'wino+splitk':
+            var, splits = var
+            need = self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, src.C + C1, 3, splits)
+            if need <= 0:
+                raise _hip.NdHipError('nd_conv_splitk_workspace_floats: ' + _hip.last_error())
+            self._splitk_floats = max(self._splitk_floats, need)
+            wq = self._packed_wino(weight, pad_c_to)
+            self.keep.append(wq)
+            self.packed_floats += wq.numel()
+            self._emit(self.lib.nd_conv3x3_winograd_splitk_nhwc, head + [wq.data_ptr()] + tail + [flags, var, splits, ('splitk', 0)],
+                       label, flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+        elif kind == 'direct+splitk':
             var, splits = var
             need = self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, src.C + C1, ksize, splits)
             if need <= 0:
@@ -662,7 +673,7 @@ class UNetPlan:
         ck = (self.device.index,) + key + (('sk%d' % _f32_splitk(),) if splitk_ok else ())
         if ck in _TUNED:
             c = _TUNED[ck]
-            return (c[0], (c[1], c[2])) if c[0] == 'direct+splitk' else c
+            return (c[0], (c[1], c[2])) if c[0] in ('direct+splitk', 'wino+splitk') else c
         stream = self._stream()
 
         def time_it(fn, args):
@@ -703,6 +714,18 @@ class UNetPlan:
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
+            if splitk_ok:
+                # conv_wino4_kernel split over K: 8x8 maps at batch 64 give 384 blocks of 24 chunks for 512 slots (half the CUs
+                # run two blocks, half one); two block rows of 12 chunks are three blocks per CU
+                names = [self.lib.nd_conv_winograd_variant_name(v) for v in range(self.lib.nd_conv_winograd_num_variants())]
+                v4 = names.index(b'nd::conv_wino4_kernel')
+                ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, 3, S), 4) for S in (2, 4)),
+                                 dtype=torch.float32, device=self.device)
+                for S in (2, 4):
+                    ms = time_it(self.lib.nd_conv3x3_winograd_splitk_nhwc, head + [wq.data_ptr()] + tail + [flags, v4, S, ws.data_ptr()])
+                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
+                        best, best_ms = ('wino+splitk', v4, S), ms
+                del ws
             del wq
         if splitk_ok:
             splits = (2, 4, 8)
@@ -712,12 +735,12 @@ class UNetPlan:
             for v in cands:
                 for S in splits:
                     ms = time_it(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v, S, ws.data_ptr()])
-                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and best[0] != 'direct+splitk')):
+                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
                         best, best_ms = ('direct+splitk', v, S), ms
             del ws
         del wp
         _TUNED[ck] = best
-        return (best[0], (best[1], best[2])) if best[0] == 'direct+splitk' else best
+        return (best[0], (best[1], best[2])) if best[0].endswith('+splitk') else best
 
     def linear(self, src_ptr, M, K, weight, bias, out_ptr, N, flags=0, label='linear'):
         assert K % 4 == 0

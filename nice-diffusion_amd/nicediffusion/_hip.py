@@ -38,6 +38,8 @@ SIGNATURES = {
                      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_conv_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                             _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    'nd_conv3x3_winograd_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                        _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_conv3x3_winograd_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],

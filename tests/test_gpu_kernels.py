@@ -890,6 +890,65 @@ def test_conv_split_k_fp32(B, C0, C1, N, H, W, ksize, opts):
     assert lib().nd_conv_splitk_workspace_floats(B, H, W, N, 32, ksize, 2) < 0      # one chunk cannot be split
 
 
+@pytest.mark.parametrize('B,C0,C1,N,H,W,opts', [(16, 768, 0, 768, 8, 8, 'bias'), (4, 256, 128, 192, 8, 8, 'rowbias+res'),
+                                                (2, 64, 64, 100, 16, 16, 'silu'), (2, 96, 160, 192, 8, 8, 'up2x+rowbias'),
+                                                (3, 64, 0, 64, 6, 10, 'res')])
+def test_conv3x3_winograd_split_k(B, C0, C1, N, H, W, opts):
+    """nd_conv3x3_winograd_splitk_nhwc (conv_wino4_kernel with block rows over the input-channel chunks + the ordered reduce)
+    against F.conv2d and the one-pass kernel: seam inside a split, N tail, per-image bias, residual, SiLU, nearest-2x input;
+    bitwise repeatable; other variants and statistics are refused."""
+    up = 'up2x' in opts
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    xa = rnd(B, C0, Hs, Ws, seed=1)
+    xb = rnd(B, C1, Hs, Ws, seed=2) if C1 else None
+    x = torch.cat([xa, xb], 1) if C1 else xa
+    C = C0 + C1
+    w, b = rnd(N, C, 3, 3, seed=3, scale=0.05), rnd(N, seed=4)
+    rb = rnd(B, N, seed=5) if 'rowbias' in opts else None
+    res = rnd(B, N, H, W, seed=6) if 'res' in opts else None
+    xin = F.interpolate(x, scale_factor=2.0, mode='nearest') if up else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    if rb is not None:
+        ref = ref + rb.double()[:, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    if 'silu' in opts:
+        ref = F.silu(ref)
+    ref = ref.float()
+    flags = (_hip.CONV_IN_UP2X if up else 0) | (_hip.CONV_SILU_OUT if 'silu' in opts else 0)
+    names = [lib().nd_conv_winograd_variant_name(v) for v in range(lib().nd_conv_winograd_num_variants())]
+    v4, v16 = names.index(b'nd::conv_wino4_kernel'), names.index(b'nd::conv_wino16_kernel<1>')
+    xad, xbd, wd, bd = nhwc(xa), (nhwc(xb) if C1 else None), pack_wino(w), b.to(DEV)
+    rbd, resd = (rb.to(DEV) if rb is not None else None), (nhwc(res) if res is not None else None)
+    p = lambda t_: None if t_ is None else t_.data_ptr()
+    tail = [p(rbd), N if rb is not None else 0, p(resd), N if res is not None else 0]
+    one = torch.full((B * H * W * N,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv3x3_winograd_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                              one.data_ptr(), N, B, H, W, N, flags, v4, None, None, 0, st()))
+    ran = 0
+    for S in (2, 4, 8):
+        need = lib().nd_conv_splitk_workspace_floats(B, H, W, N, C, 3, S)
+        if need < 0:
+            assert C // 32 < 2
+            continue
+        ws = torch.full((need,), float('nan'), device=DEV)
+        out = torch.full((B * H * W * N,), float('nan'), device=DEV)
+        _hip.check(lib().nd_conv3x3_winograd_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                                         out.data_ptr(), N, B, H, W, N, flags, v4, S, ws.data_ptr(), st()), 'S=%d' % S)
+        ran += 1
+        got = from_nhwc(out, B, H, W, N)
+        assert torch.isfinite(got).all(), S
+        assert (got - ref).abs().max().item() < 2e-4, (S, (got - ref).abs().max().item())
+        assert (out - one).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), S
+        out2 = torch.full_like(out, float('nan'))
+        _hip.check(lib().nd_conv3x3_winograd_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                                         out2.data_ptr(), N, B, H, W, N, flags, v4, S, ws.data_ptr(), st()))
+        assert torch.equal(out, out2), S
+    assert ran >= 2
+    assert lib().nd_conv3x3_winograd_splitk_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), *tail,
+                                                 one.data_ptr(), N, B, H, W, N, flags, v16, 2, ws.data_ptr(), st()) != 0
+
+
 @pytest.mark.parametrize('B,C,N,H,W', [(2, 32, 48, 16, 16), (3, 64, 64, 8, 12)])
 def test_stride2_conv_via_space_to_depth(B, C, N, H, W):
     """Downsample's stride-2 3x3 conv (model.py:103-108) = stride-1 3x3 conv of the space-to-depth tensor with the
