@@ -252,7 +252,7 @@ def test_committed_tune_caches_match_the_built_library():
             kind, var = v[0], v[1]
             if kind.startswith('bf16'):
                 assert 0 <= var < lib.nd_conv_bf16_num_variants() and not lib.nd_conv_bf16_variant_name(var).startswith(b'(retired)')
-            elif kind == 'wino':
+            elif kind in ('wino', 'wino+splitk'):
                 assert 0 <= var < lib.nd_conv_winograd_num_variants() and \
                     not lib.nd_conv_winograd_variant_name(var).startswith(b'(retired)')
             else:
