@@ -130,7 +130,7 @@ def _traffic_table():
 
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
             'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc',
-            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc')
+            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc')
 
 
 def roofline_from(rows, lib, dtype='fp32', esize=4):

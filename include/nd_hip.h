@@ -94,6 +94,16 @@ int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int
 int nd_conv_num_variants(void);
 /* The variant nd_conv_nhwc picks for a shape when `variant` < 0 (host-only query; < 0 on error), and a variant's
  * block tile (pixels x output channels) and thread count.  Used by bench.py to attribute launches to kernels. */
+/* 1x1 convolution on a flat pixel list by the two-blocks-per-CU GEMM (variant 14 of nd_conv_nhwc; its restrictions apply)
+ * that also leaves the per-channel partial statistics of its output behind: chstats [NI][H*W/128][sum | sum of squares][N]
+ * in fp32, one row per 128-pixel run of an image, every row written by every launch (no zeroing, no atomics);
+ * nd_groupnorm_stats_from_partials folds them -- the attention block's output projection + residual (model.py:291) feeds
+ * the next block's in_norm (model.py:190), which then needs no pass over the tensor.  rows per image:
+ * nd_conv1x1_stats_rows (0: the shape cannot -- H*W % 128, NI*H*W % 256, N % 4 must be 0); ldo must equal N. */
+int nd_conv1x1_stats_rows(int NI, int H, int W, int N);
+int nd_conv1x1_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                          const float* w, const float* bias, const float* residual, int ldr, float* out, int ldo,
+                          int NI, int H, int W, int N, int flags, float* chstats, nd_stream_t stream);
 /* The same convolution split over K, for layers whose output has too few tiles to fill the chip and whose contraction is
  * long (7x7 .. 16x16 maps at small batch; the reference runs them as ordinary Conv2d, model.py:166-182): `splits` (2..16)
  * block rows each run a range of whole 32-channel chunks of the (concatenated) input and leave raw accumulators in

@@ -833,7 +833,7 @@ static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, cons
                          const float* residual, int ldr, float* out, int ldo,
                          int NI, int H, int W, int N, int ksize, int flags, int variant,
                          const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream, int splits = 1,
-                         float* workspace = nullptr) {
+                         float* workspace = nullptr, float* chstats = nullptr) {
     ND_REQUIRE(x0 && w && out, fn, "null pointer");
     ND_REQUIRE(ksize == 1 || ksize == 3, fn, "ksize must be 1 or 3");
     ND_REQUIRE(NI > 0 && H > 0 && W > 0 && N > 0 && C0 > 0 && C1 >= 0, fn, "bad shape");
@@ -907,6 +907,14 @@ static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, cons
     a.nt = (N + V.bn() - 1) / V.bn();
     a.ngroup = pick_ngroup(a.nt, (size_t)V.bn() * (C0 + C1) * taps * sizeof(float), (size_t)M * (C0 + C1) * sizeof(float));
     a.vec_ok = 0; a.nhi = 0; a.zero = nullptr; a.chstats = nullptr; a.mbi = 1;
+    if (chstats) {
+        // output statistics: gemm4_kernel only (variant 14), one fp32 row per (image, 128-pixel run)
+        ND_REQUIRE(best_v == 14 && flat && gnA == nullptr && splits <= 1, fn, "output statistics: the two-blocks-per-CU GEMM (variant 14) only, no fused GroupNorm");
+        ND_REQUIRE(((long)H * W) % 128 == 0 && (N & 3) == 0 && ldo == N && aligned16(out) && aligned16(chstats) &&
+                   (!bias || aligned16(bias)) && (!residual || ((ldr & 3) == 0 && aligned16(residual))), fn,
+                   "output statistics: H*W % 128 == 0, N % 4 == 0, ldo == N, 16-byte aligned rows");
+        a.chstats = chstats; a.mbi = (int)(((long)H * W) / 128);
+    }
     a.silu_out = ((flags & ND_CONV_SILU_OUT) && a.ksplit <= 1) ? 1 : 0;
     a.gnA = gnA; a.gnB = gnB; a.ld_gn = ld_gn; a.gn_silu = (flags & ND_CONV_GN_SILU) ? 1 : 0; a.gn_hw = 0;
     if (gnA) {
@@ -952,6 +960,25 @@ extern "C" int nd_conv_nhwc(const float* x0, int C0, int ldx0, const float* x1, 
                             const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream) {
     return conv_f32_impl("nd_conv_nhwc", x0, C0, ldx0, x1, C1, ldx1, w, bias, rowbias, ld_rowbias, residual, ldr, out, ldo, NI, H, W,
                          N, ksize, flags, variant, gnA, gnB, ld_gn, stream);
+}
+
+// 1x1 convolution by gemm4_kernel (variant 14) that also leaves the per-channel partial statistics of its output behind:
+// chstats [NI][H*W/128][sum | sum of squares][N] in fp32, one row per 128-pixel run of an image, every row written by every
+// launch; nd_groupnorm_stats_from_partials folds them (the attention block's output projection + residual feeds the next
+// GroupNorm, model.py:291,190).  nd_conv1x1_stats_rows gives the rows per image (0: this shape cannot).
+extern "C" int nd_conv1x1_stats_rows(int NI, int H, int W, int N) {
+    if (NI <= 0 || H <= 0 || W <= 0 || N <= 0) return ND_E_ARG;
+    const long hw = (long)H * W;
+    return (hw % 128 == 0 && ((long)NI * hw) % 256 == 0 && (N & 3) == 0) ? (int)(hw / 128) : 0;
+}
+
+extern "C" int nd_conv1x1_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
+                                     const float* w, const float* bias, const float* residual, int ldr, float* out, int ldo,
+                                     int NI, int H, int W, int N, int flags, float* chstats, nd_stream_t stream) {
+    const char* fn = "nd_conv1x1_stats_nhwc";
+    ND_REQUIRE(chstats != nullptr, fn, "chstats is null");
+    return conv_f32_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, nullptr, 0, residual, ldr, out, ldo, NI, H, W, N, 1, flags, 14,
+                         nullptr, nullptr, 0, stream, 1, nullptr, chstats);
 }
 
 // The same convolution split over K: `splits` (2..16) block rows each run a range of 32-channel chunks of the input and

@@ -18,7 +18,7 @@
 
 namespace nd {
 
-template <bool GN>
+template <bool GN, bool STATS = false>          // STATS: also leave the per-channel partial statistics of the output behind (p.chstats)
 __global__ void __launch_bounds__(256, 2)
     gemm4_kernel(const ConvArgs p) {
     constexpr int BM = 256, BN = 128, TM = 4, TN = 2;
@@ -234,6 +234,49 @@ __global__ void __launch_bounds__(256, 2)
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
     const bool vec_ok = ((p.ldo & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    if constexpr (STATS) {
+        // GroupNorm statistics of the output for free (the attention block's output projection + residual feeds the next
+        // block's in_norm, model.py:291,190): per channel, the sum / sum of squares of what this wave row (128 consecutive
+        // pixels of ONE image: the host requires H*W % 128 == 0) stores, one fp32 row per (image, 128-pixel run):
+        // chstats [NI][mbi][sum | sum of squares][N], plain stores, every entry written by every launch (no atomics);
+        // folded by nd_groupnorm_stats_from_partials.  The host guarantees M % 256 == 0, N % 4 == 0 and aligned rows.
+        const int mrow = m0 + wm * (TM * 32);
+        const int hw = p.mbi * 128;
+        const int img = mrow / hw;
+        float* prow = p.chstats + (((size_t)img * p.mbi + (mrow - img * hw) / 128) * 2) * p.N;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+                if (n + 3 < p.N) {
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const size_t opix = (size_t)(mrow + mi * 32 + l31);
+                        f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2], acc[mi][ni][4 * g4 + 3]};
+                        if (p.bias) v += bv;
+                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + opix * p.ldr + n);
+                        if (p.silu_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + opix * p.ldo + n) = v;
+                        ssum += v;
+                        ssq += v * v;
+                    }
+                }
+                sum8_over_32_lanes(ssum, ssq);            // DPP adds (nd_conv_common.h); the totals sit in lanes 16..31 / 48..63
+                if (l31 == 31 && n + 3 < p.N) {
+                    *reinterpret_cast<f32x4*>(prow + n) = ssum;
+                    *reinterpret_cast<f32x4*>(prow + p.N + n) = ssq;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + l31;
@@ -275,7 +318,12 @@ __global__ void __launch_bounds__(256, 2)
 
 int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)64 * 1024;
-    if (a.gnA) {
+    if (a.chstats) {          // (the host admits statistics without a fused GroupNorm only)
+        auto kern = gemm4_kernel<false, true>;
+        static bool attr_set[kMaxDevices] = {};
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    } else if (a.gnA) {
         auto kern = gemm4_kernel<true>;
         static bool attr_set[kMaxDevices] = {};
         if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;

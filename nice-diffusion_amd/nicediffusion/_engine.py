@@ -397,8 +397,21 @@ class UNetPlan:
                            flops=fl, variant=('wino', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         else:
             wp = self._packed(weight, pad_c_to)
-            self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var] + gn, label, flops=fl,
-                       variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+            rows = 0
+            if ksize == 1 and var == 14 and want_stats and gn[0] is None and rowbias is None and out.ld == N and flags == 0 and \
+                    _epilogue_stats_mode() != '0':
+                # gemm4_kernel's epilogue leaves the per-channel partial statistics of its output behind (the attention
+                # block's output projection + residual feeds the next block's in_norm): no pass over `out`
+                rows = self.lib.nd_conv1x1_stats_rows(NI, H, W, N)
+            if rows > 0:
+                ph = ('chpart', self._cs_floats)
+                out.cs = (ph, rows)
+                self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
+                self._emit(self.lib.nd_conv1x1_stats_nhwc, head + [wp.data_ptr(), tail[0]] + tail[3:] + [flags, ph], label, flops=fl,
+                           variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
+            else:
+                self._emit(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, var] + gn, label, flops=fl,
+                           variant=('direct', var), ksize=ksize, shape=(NI, H, W, src.C + C1, N))
         self.flops += fl
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         if tmp is not None:

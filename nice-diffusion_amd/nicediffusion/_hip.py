@@ -36,6 +36,7 @@ SIGNATURES = {
     'nd_embedding_add_silu': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'nd_conv_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                      _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    'nd_conv1x1_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_conv_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                             _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_conv3x3_winograd_splitk_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
@@ -92,6 +93,7 @@ _SPECIAL = {
     'nd_conv_bf16_max_weight_read': ([_i, _i, _i, _i, _i], _i64),
     'nd_conv_bf16_splitk_workspace_floats': ([_i, _i, _i, _i, _i, _i, _i], _i64),
     'nd_conv_splitk_workspace_floats': ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    'nd_conv1x1_stats_rows': ([_i, _i, _i, _i], _i),
     'nd_conv_bf16_num_variants': ([], _i),
     'nd_conv_bf16_variant_layout': ([_i], _i),
     'nd_conv_bf16_variant_name': ([_i], ctypes.c_char_p),

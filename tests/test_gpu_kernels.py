@@ -890,6 +890,54 @@ def test_conv_split_k_fp32(B, C0, C1, N, H, W, ksize, opts):
     assert lib().nd_conv_splitk_workspace_floats(B, H, W, N, 32, ksize, 2) < 0      # one chunk cannot be split
 
 
+@pytest.mark.parametrize('B,C0,C1,N,H,W,res', [(4, 384, 0, 384, 32, 32, True), (2, 64, 64, 100, 16, 16, True), (8, 96, 0, 64, 8, 16, False)])
+def test_conv1x1_gemm4_epilogue_statistics(B, C0, C1, N, H, W, res):
+    """nd_conv1x1_stats_nhwc: the bits of nd_conv_nhwc's variant 14 (gemm4_kernel) plus one fp32 row per (image, 128-pixel
+    run) with the per-channel sum / sum of squares of the values it stored; nd_groupnorm_stats_from_partials folds the rows
+    into what the float64 statistics kernel computes on the output."""
+    C = C0 + C1
+    xa = rnd(B, C0, H, W, seed=1)
+    xb = rnd(B, C1, H, W, seed=2) if C1 else None
+    w, b = rnd(N, C, seed=3, scale=0.05), rnd(N, seed=4)
+    r = rnd(B, N, H, W, seed=5) if res else None
+    x = torch.cat([xa, xb], 1) if C1 else xa
+    ref = F.conv2d(x.double(), w.double()[:, :, None, None], b.double())
+    if res:
+        ref = ref + r.double()
+    xad, xbd, wd, bd, rd = nhwc(xa), (nhwc(xb) if C1 else None), pack_w(w), b.to(DEV), (nhwc(r) if res else None)
+    p = lambda t_: None if t_ is None else t_.data_ptr()
+    rows = lib().nd_conv1x1_stats_rows(B, H, W, N)
+    assert rows == H * W // 128
+    plain = torch.full((B * H * W * N,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), None, 0, p(rd), N if res else 0,
+                                  plain.data_ptr(), N, B, H, W, N, 1, 0, 14, None, None, 0, st()))
+    out = torch.full((B * H * W * N,), float('nan'), device=DEV)
+    ps = torch.full((B * rows * 2 * N,), float('nan'), device=DEV)
+    _hip.check(lib().nd_conv1x1_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), p(rd), N if res else 0,
+                                           out.data_ptr(), N, B, H, W, N, 0, ps.data_ptr(), st()))
+    assert torch.equal(out, plain)
+    got = from_nhwc(out, B, H, W, N)
+    assert (got - ref.float()).abs().max().item() < 2e-4
+    assert torch.isfinite(ps).all()                       # every row is written by every launch
+    c = ps.view(B, rows, 2, N).double().sum(1).cpu()      # [B][2][N]
+    g64 = got.double()
+    assert (c[:, 0] - g64.sum((2, 3))).abs().max().item() < 1e-3 * max(1.0, g64.sum((2, 3)).abs().max().item())
+    assert ((c[:, 1] - (g64 ** 2).sum((2, 3))).abs() / (g64 ** 2).sum((2, 3))).max().item() < 1e-5
+    if N % 32 == 0:
+        a_ = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), N, rows, None, 0, 0, a_.data_ptr(), B, 32, st()))
+        b2 = gn_sums(*gn_stats(out.data_ptr(), N, N, None, 0, 0, None, 0, B, H * W), B).flatten().to(DEV)
+        assert ((a_ - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
+    ps2 = torch.full_like(ps, float('nan'))
+    _hip.check(lib().nd_conv1x1_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), p(rd), N if res else 0,
+                                           out.data_ptr(), N, B, H, W, N, 0, ps2.data_ptr(), st()))
+    assert torch.equal(ps, ps2)                           # fixed-order DPP sums: bitwise repeatable
+    # shapes without whole 128-pixel runs per image have no rows; ldo must equal N
+    assert lib().nd_conv1x1_stats_rows(B, 6, 10, N) == 0
+    assert lib().nd_conv1x1_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), p(rd), N if res else 0,
+                                       out.data_ptr(), N + 4, B, H, W, N, 0, ps2.data_ptr(), st()) != 0
+
+
 @pytest.mark.parametrize('B,C0,C1,N,H,W,opts', [(16, 768, 0, 768, 8, 8, 'bias'), (4, 256, 128, 192, 8, 8, 'rowbias+res'),
                                                 (2, 64, 64, 100, 16, 16, 'silu'), (2, 96, 160, 192, 8, 8, 'up2x+rowbias'),
                                                 (3, 64, 0, 64, 6, 10, 'res')])

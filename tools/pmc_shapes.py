@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
             'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc',
-            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc')
+            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc')
 CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel',
                 'gemm_stream_kernel', 'conv_bf16_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_bf16q_kernel', 'gemm_f32_kernel',
                 'gemm4_kernel')
