@@ -120,7 +120,7 @@ def _traffic_table():
     """Per-shape HBM traffic of the conv kernels from the PMC passes (tools/pmc_shapes.py -> profiles/rNN_pmc_shapes.json:
     one entry per (kernel kind, variant, ksize, NI, H, W, Cin, N) with FETCH_SIZE x2 + WRITE_SIZE per launch); rocprofv3 cannot run
     inside this process, so the table is regenerated by that script and looked up by the shapes actually launched."""
-    for name in ('r04_pmc_shapes.json', 'r03_pmc_shapes.json', 'r02_pmc_shapes.json'):
+    for name in ('r05_pmc_shapes.json', 'r04_pmc_shapes.json', 'r03_pmc_shapes.json', 'r02_pmc_shapes.json'):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', name))), name
         except (OSError, ValueError):
@@ -130,7 +130,10 @@ def _traffic_table():
 
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
             'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc',
-            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc')
+            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc', 'nd_conv3x3_winograd_f4_nhwc')
+# flops EXECUTED on the matrix pipe / direct-convolution flops: Winograd F(2x2,3x3) runs 16 positions per 4 output pixels
+# (4/9), F(4x4,3x3) 36 per 16 (1/4)
+EXEC_FRACTION = {'wino': 4.0 / 9.0, 'wf4': 1.0 / 4.0}
 
 
 def roofline_from(rows, lib, dtype='fp32', esize=4):
@@ -142,7 +145,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
 
     def executed(r):
-        return r['flops'] * (4.0 / 9.0 if r['variant'] and r['variant'][0] == 'wino' else 1.0)
+        return r['flops'] * (EXEC_FRACTION.get(r['variant'][0], 1.0) if r['variant'] else 1.0)
     groups = {}
     for r in rows:
         if r['fn'] not in conv_fns or not r.get('variant'):
@@ -161,6 +164,10 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         lib.nd_conv_winograd_variant_info(var, *(ctypes.byref(v) for v in (bm, bn, nt, nsub, apf)))
         kname = '{} (Winograd F(2x2,3x3) on fp32 MFMA; {} px x {} ch per block, {} threads)'.format(
             lib.nd_conv_winograd_variant_name(var).decode(), bm.value, bn.value, nt.value)
+    elif kind == 'wf4':
+        lib.nd_conv_winograd_f4_variant_info(var, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
+        kname = '{} (Winograd F(4x4,3x3) on fp32 MFMA v_mfma_f32_16x16x4_f32; {} px x {} ch per workgroup, {} threads)'.format(
+            lib.nd_conv_winograd_f4_variant_name(var).decode(), bm.value, bn.value, nt.value)
     elif kind == 'bf16':
         lib.nd_conv_bf16_variant_info(max(var, 0), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         kname = '{}<{}x{} tile, {} threads, {} taps> ({})'.format(
@@ -201,7 +208,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
         'frac': round(achieved / peak, 4), 'traffic': traffic,
         'kernel': kname,
         'note': 'achieved = flops EXECUTED on the matrix pipe / time (Winograd F(2x2,3x3): 4/9 of the direct-convolution '
-                'flops); algorithmic_equivalent = direct-convolution flops / time',
+                'flops, F(4x4,3x3): 1/4); algorithmic_equivalent = direct-convolution flops / time',
         'algorithmic_equivalent': round(g['flops'] / sec / 1e12, 2),
         'launches_per_forward': g['launches'], 'avg_launch_ms': round(g['ms'] / g['launches'], 4),
         'flops_per_launch_avg': g['flops'] / g['launches'],

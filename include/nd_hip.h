@@ -168,6 +168,32 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
                              int NI, int H, int W, int N, int flags, int variant,
                              const float* gnA, const float* gnB, int ld_gn, nd_stream_t stream);
 
+/* Winograd F(4x4,3x3) form of the same 3x3 stride-1 pad-1 convolution (model.py:173-177,194,209): 36 transform positions
+ * per 4x4 output tile = a quarter of the direct convolution's multiplies, 0.5625 x the matrix instructions of the F(2x2,3x3)
+ * form; fp32 throughout (exact-fp32 MFMA; data-side transform constants 1, 2, 4, 5, 8, weight-side 1/4 .. 1/24 folded at
+ * repack in float64).  Numerically the looser of the two forms (about 5x the rounding error of F(2x2,3x3): 7e-6 per forward
+ * of the 64x64 preset, 1.4e-4 after its 25-step chain against the reference's 1e-3; profiles/r05_f4_numerics_preset64.txt),
+ * so callers choose it per layer (the plan tuner does; ND_WINOGRAD_F4=0 keeps F(2x2,3x3) everywhere).
+ * conv_wf4_kernel: 6 waves, 256 output pixels x 48 channels per block, two blocks per CU.  Restrictions: ONE source tensor
+ * (no concatenation) of whole 32-channel chunks; H and W multiples of 4, at least 12x12 (16x16-pixel blocks) or exactly 8x8
+ * (four images per block); flags IN_UP2X / RES_UP2X / SILU_OUT; no fused GroupNorm.  `w` from
+ * nd_repack_conv_weight_winograd_f4 (nd_conv_winograd_f4_weight_floats floats).
+ * chstats | NULL: per-channel partial statistics of the output, [NI][rows][sum | sum of squares][N] fp32 with
+ *   rows = nd_conv_winograd_f4_stats_rows(variant, NI, H, W) per image, every entry written by every launch (needs ldo == N);
+ *   nd_groupnorm_stats_from_partials folds them.
+ * splits > 1: split over K as nd_conv3x3_winograd_splitk_nhwc (same workspace size, same restrictions; no chstats). */
+int nd_conv_winograd_f4_num_variants(void);
+const char* nd_conv_winograd_f4_variant_name(int variant);
+int nd_conv_winograd_f4_variant_info(int variant, int* bm, int* bn, int* threads);
+int64_t nd_conv_winograd_f4_weight_floats(int variant, int N, int C);
+int64_t nd_conv_winograd_f4_max_weight_read(int variant, int N, int C);
+int nd_repack_conv_weight_winograd_f4(const float* w_oihw, float* w_out, int N, int C, int variant, nd_stream_t stream);
+int nd_conv_winograd_f4_stats_rows(int variant, int NI, int H, int W);
+int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, const float* w, const float* bias,
+                                const float* rowbias, int ld_rowbias, const float* residual, int ldr, float* out, int ldo,
+                                int NI, int H, int W, int N, int flags, int variant, float* chstats, int splits,
+                                float* workspace, nd_stream_t stream);
+
 /* ---- bf16 path (BASELINE configs[3], [4]): bf16 activations and weights in HBM, fp32 accumulation -------------------
  * nd_conv_bf16_nhwc: the same convolution and fused options as nd_conv_nhwc (ksize 1 | 3; two-source input, bias,
  *   rowbias, residual, ND_CONV_IN_UP2X / RES_UP2X / SILU_OUT) on v_mfma_f32_32x32x16_bf16.  x0 / x1 / residual / out

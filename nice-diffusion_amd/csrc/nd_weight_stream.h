@@ -31,6 +31,12 @@ constexpr int kWinoAhead = 1;             // conv_wino_kernel, conv_wino16(p)_ke
 constexpr int kWinoDmaAhead = 2;          // conv_wino16g_kernel: two k-steps
 constexpr int kWinoWaveAhead = 1;         // conv_winow_kernel: one half-step, never more than one k-step
 
+// ---- Winograd F(4x4,3x3) form (nd_conv_winograd_f4_weight_floats): chunk = 16 channels, 4 k4-steps of 6 positions per chunk,
+//      n block and transform row
+constexpr int kWf4PadChunks = 1;
+constexpr int kWf4StepsPerChunk = 4;
+constexpr int kWf4Ahead = 1;              // conv_wf4_kernel: one k4-step
+
 // ---- bf16 forms (nd_conv_bf16_weight_elems): chunk = 64 channels; taps * 4 fragments (32x32x16 layout) or taps * 2
 //      fragments per 16-channel n tile (16x16x32 layout) per chunk
 constexpr int kBf16PadChunks = 2;

@@ -37,6 +37,7 @@ def _tune_stamp():
     variant NUMBER; a rebuilt library may number its kernels differently)."""
     lib = _hip.load()
     names = [lib.nd_conv_winograd_variant_name(v).decode() for v in range(lib.nd_conv_winograd_num_variants())]
+    names += [lib.nd_conv_winograd_f4_variant_name(v).decode() for v in range(lib.nd_conv_winograd_f4_num_variants())]
     names += [lib.nd_conv_bf16_variant_name(v).decode() for v in range(lib.nd_conv_bf16_num_variants())]
     return 'v{}:d{}:{}'.format(lib.nd_version(), lib.nd_conv_num_variants(), '|'.join(names))
 
@@ -174,6 +175,16 @@ def _f32_splitk():
     that way where it is faster -- the 7x7 / 14x14 layers of the EMNIST preset at batch 4 run 16-64 blocks of a 1152-MFMA
     serial chain otherwise; 0: never; 2: wherever the form exists (tests)."""
     return int(os.environ.get('ND_F32_SPLITK', '1'))
+
+
+def _winograd_f4():
+    """ND_WINOGRAD_F4 (default 1): fp32 3x3 convolutions on maps that are multiples of 4 are also measured on the Winograd
+    F(4x4,3x3) kernel (nd_conv3x3_winograd_f4_nhwc: a quarter of the direct multiplies, 0.5625 x the matrix instructions of
+    F(2x2,3x3)) and run there where it is faster.  It is the numerically looser form -- about 5x the rounding error of
+    F(2x2,3x3): 7e-6 per forward of the 64x64 preset, 1.4e-4 after its own 25-step chain against the reference's 1e-3
+    (profiles/r05_f4_numerics_preset64.txt; the GPU-measured numbers are asserted in tests/test_gpu_model.py) -- so
+    0 keeps F(2x2,3x3) everywhere; 2: wherever the form exists (tests)."""
+    return int(os.environ.get('ND_WINOGRAD_F4', '1'))
 
 
 def _fuse_gn_mode():
@@ -316,6 +327,20 @@ class UNetPlan:
                    'nd_repack_conv_weight_winograd')
         return out
 
+    def _packed_wf4(self, weight, pad_c_to=None):
+        """3x3 weight -> Winograd F(4x4,3x3) domain (U = G g G^T, float64 rounded once) in conv_wf4_kernel's fragment order."""
+        w = weight.detach().contiguous()
+        N, C = w.shape[0], w.shape[1]
+        if pad_c_to is not None and pad_c_to != C:
+            wp = torch.zeros((N, pad_c_to, 3, 3), dtype=w.dtype, device=w.device)
+            wp[:, :C] = w
+            w, C = wp, pad_c_to
+        n = self.lib.nd_conv_winograd_f4_weight_floats(0, N, C)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _hip.check(self.lib.nd_repack_conv_weight_winograd_f4(w.data_ptr(), out.data_ptr(), N, C, 0, self._stream()),
+                   'nd_repack_conv_weight_winograd_f4')
+        return out
+
     def conv(self, src, weight, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
              residual=None, flags=0, label='conv', pad_c_to=None, want_stats=False):
         """Emit one convolution.  ``src`` (and optional ``src2``, concatenated after it) are Acts; ``weight`` is the
@@ -355,8 +380,32 @@ class UNetPlan:
                 0 if residual is None else residual.ld, out.ptr, out.ld, NI, H, W, N]
         fl = 2 * NI * H * W * N * ksize * ksize * (src.C + C1)
         key = (NI, H, W, src.C + C1, N, ksize, flags, rowbias is not None, residual is not None, gn[0] is not None)
-        kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags, gn)
-        if kind == 'wino+splitk':
+        # does a GroupNorm that reads `out` use per-channel partial statistics at all (small tensors take the one-launch norm)?
+        stats_wanted = bool(want_stats and gn[0] is None and out.ld == N and _epilogue_stats_mode() != '0' and
+                            NI * H * W * N > _gn_fused_max_elems(False))
+        kind, var = self._pick_impl(key, fl, weight, pad_c_to, head, tail, flags, gn, single=src2 is None, out=out,
+                                    stats_wanted=stats_wanted)
+        if kind in ('wf4', 'wf4+splitk'):
+            splits = var[1] if kind == 'wf4+splitk' else 1
+            wq = self._packed_wf4(weight, pad_c_to)
+            self.keep.append(wq)
+            self.packed_floats += wq.numel()
+            ph, ws = None, None
+            if splits > 1:
+                need = self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, src.C, 3, splits)
+                if need <= 0:
+                    raise _hip.NdHipError('nd_conv_splitk_workspace_floats: ' + _hip.last_error())
+                self._splitk_floats = max(self._splitk_floats, need)
+                ws = ('splitk', 0)
+            elif stats_wanted:
+                rows = self.lib.nd_conv_winograd_f4_stats_rows(0, NI, H, W)
+                if rows > 0:
+                    ph = ('chpart', self._cs_floats)
+                    out.cs = (ph, rows)
+                    self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
+            self._emit(self.lib.nd_conv3x3_winograd_f4_nhwc, head[:3] + [wq.data_ptr()] + tail + [flags, 0, ph, splits, ws], label,
+                       flops=fl, variant=('wf4', 0), ksize=ksize, shape=(NI, H, W, src.C, N))
+        elif kind == 'wino+splitk':
             var, splits = var
             need = self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, src.C + C1, 3, splits)
             if need <= 0:
@@ -672,7 +721,7 @@ class UNetPlan:
             return choice[1], ('splitk', choice[2])
         return choice[1], ('stats' if choice[0] == 'bf16+stats' else 'plain')
 
-    def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn):
+    def _pick_impl(self, key, flops, weight, pad_c_to, head, tail, flags, gn, single=True, out=None, stats_wanted=False):
         """(kind, variant) for one conv launch.  Measured on the device: two bursts of 6 launches per candidate -- every direct
         tile shape that fits and, for 3x3 on even sizes, the Winograd variants -- best kept and cached per shape.
         ND_AUTOTUNE=0 falls back to the library's cost model (direct kernel); ND_WINOGRAD=0 excludes Winograd."""
@@ -683,10 +732,13 @@ class UNetPlan:
             not (flags & _hip.CONV_RES_UP2X) and (pad_c_to is None or pad_c_to % 32 == 0)
         if not _autotune_enabled() or flops < (2e7 if splitk_ok else 2e8):
             return heur
-        ck = (self.device.index,) + key + (('sk%d' % _f32_splitk(),) if splitk_ok else ())
+        f4_ok = ksize == 3 and _winograd_f4() and single and gn[0] is None and C % 32 == 0 and \
+            (pad_c_to is None or pad_c_to % 32 == 0) and self.lib.nd_conv_winograd_f4_stats_rows(0, NI, H, W) > 0
+        ck = (self.device.index,) + key + (('sk%d' % _f32_splitk(),) if splitk_ok else ()) + \
+            (('f4%d%s' % (_winograd_f4(), 's' if stats_wanted else ''),) if f4_ok else ())
         if ck in _TUNED:
             c = _TUNED[ck]
-            return (c[0], (c[1], c[2])) if c[0] in ('direct+splitk', 'wino+splitk') else c
+            return (c[0], (c[1], c[2])) if c[0].endswith('+splitk') else c
         stream = self._stream()
 
         def time_it(fn, args):
@@ -714,17 +766,28 @@ class UNetPlan:
             return best_t
 
         best, best_ms = heur, None
+        # a candidate that leaves no per-channel statistics behind costs the norms that read its output one pass over it
+        # (nd_groupnorm_channel_partials_nhwc); only conv_wino4_kernel and conv_wf4_kernel (one pass, not split) write them
+        pass_ms = 0.0
+        if stats_wanted and f4_ok and out is not None:
+            nb = self.lib.nd_groupnorm_stats_blocks(NI, H * W, N, self.dt)
+            if nb > 0:
+                rows_t = torch.empty(NI * nb * 2 * N, dtype=torch.float32, device=self.device)
+                pass_ms = time_it(self.lib.nd_groupnorm_channel_partials_nhwc, [out.ptr, N, out.ld, rows_t.data_ptr(), NI, H * W, self.dt]) or 0.0
+                del rows_t
         wp = self._packed(weight, pad_c_to)
         self.keep.pop()                               # tuning copy; the chosen kind is packed again by the caller
         self.packed_floats -= wp.numel()
         for v in range(self.lib.nd_conv_num_variants()):
             ms = time_it(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v] + gn)
-            if ms is not None and (best_ms is None or ms < best_ms):
-                best, best_ms = ('direct', v), ms
+            if ms is not None and (best_ms is None or ms + pass_ms < best_ms):
+                best, best_ms = ('direct', v), ms + pass_ms
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
             for v in range(self.lib.nd_conv_winograd_num_variants()):      # (retired variant numbers refuse the launch)
                 ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
+                if ms is not None and self.lib.nd_conv_winograd_variant_name(v) != b'nd::conv_wino4_kernel':
+                    ms += pass_ms
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
             if splitk_ok:
@@ -736,8 +799,28 @@ class UNetPlan:
                                  dtype=torch.float32, device=self.device)
                 for S in (2, 4):
                     ms = time_it(self.lib.nd_conv3x3_winograd_splitk_nhwc, head + [wq.data_ptr()] + tail + [flags, v4, S, ws.data_ptr()])
+                    if ms is not None:
+                        ms += pass_ms
                     if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
                         best, best_ms = ('wino+splitk', v4, S), ms
+                del ws
+            del wq
+        if f4_ok:
+            # Winograd F(4x4,3x3): one pass, and -- where the m tiles do not fill the chip (16x16 and 8x8 maps at batch 64:
+            # 384 / 128 workgroups for 256 CUs) -- split over K
+            wq = self._packed_wf4(weight, pad_c_to)
+            f4_args = head[:3] + [wq.data_ptr()] + tail + [flags, 0]
+            force = _winograd_f4() == 2 and not best[0].startswith('wf4')
+            ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None, 1, None])
+            if ms is not None and (best_ms is None or ms < best_ms or force):
+                best, best_ms = ('wf4', 0), ms
+            if _f32_splitk() and NI * H * W <= 32768 and C >= 256 and N % 4 == 0 and not (flags & _hip.CONV_RES_UP2X):
+                ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, 3, S), 4) for S in (2, 4)),
+                                 dtype=torch.float32, device=self.device)
+                for S in (2, 4):
+                    ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None, S, ws.data_ptr()])
+                    if ms is not None and (best_ms is None or ms + pass_ms < best_ms):
+                        best, best_ms = ('wf4+splitk', 0, S), ms + pass_ms
                 del ws
             del wq
         if splitk_ok:
@@ -748,6 +831,8 @@ class UNetPlan:
             for v in cands:
                 for S in splits:
                     ms = time_it(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v, S, ws.data_ptr()])
+                    if ms is not None:
+                        ms += pass_ms
                     if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
                         best, best_ms = ('direct+splitk', v, S), ms
             del ws

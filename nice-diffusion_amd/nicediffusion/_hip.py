@@ -43,6 +43,9 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_conv3x3_winograd_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    'nd_conv3x3_winograd_f4_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    'nd_repack_conv_weight_winograd_f4': [_vp, _vp, _i, _i, _i, _vp],
+    'nd_conv_winograd_f4_stats_rows': [_i, _i, _i, _i],
     'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     'nd_conv3x3_winograd_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                        _i, _i, _i, _i, _i, _vp, _vp],
@@ -107,6 +110,11 @@ _SPECIAL = {
     'nd_conv_winograd_stats_floats': ([_i, _i, _i, _i, ctypes.POINTER(_i)], _i64),
     'nd_conv_winograd_variant_info': ([_i] + [ctypes.POINTER(_i)] * 5, _i),
     'nd_conv_winograd_variant_name': ([_i], ctypes.c_char_p),
+    'nd_conv_winograd_f4_num_variants': ([], _i),
+    'nd_conv_winograd_f4_variant_name': ([_i], ctypes.c_char_p),
+    'nd_conv_winograd_f4_variant_info': ([_i] + [ctypes.POINTER(_i)] * 3, _i),
+    'nd_conv_winograd_f4_weight_floats': ([_i, _i, _i], _i64),
+    'nd_conv_winograd_f4_max_weight_read': ([_i, _i, _i], _i64),
     'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),
     'nd_conv_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_last_error': ([], ctypes.c_char_p),
