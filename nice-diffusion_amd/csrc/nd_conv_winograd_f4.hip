@@ -50,12 +50,66 @@ struct Wf4Geo {
     static constexpr int TW = 4 << TWL2, TH = 4 << THL2;   // output pixels of a block (per image)
     static constexpr int HW = TW + 2, HH = TH + 2;         // halo
     static constexpr int NG = (1 << NIBL) * HH * GW;       // 256-byte groups (4 pixels x 64 B) per halo buffer
-    static constexpr int NDMA = (NG + 23) / 24;            // DMA rounds per chunk: 6 waves x 1 KiB (4 groups) each
-    static constexpr int BUF = NDMA * 6 * 1024;            // bytes per halo buffer
+    static constexpr int NDMA = (NG + 47) / 48;            // DMA rounds per chunk: 12 waves x 1 KiB (4 groups) each
+    static constexpr int BUF = NDMA * 12 * 1024;           // bytes per halo buffer
     static_assert(GW * 4 >= HW, "a halo row fits its groups");
-    static_assert(2 * BUF <= kWf4ExchangeBytes, "the exchange buffer sets the LDS size");
+    static_assert(2 * BUF <= 2 * kWf4ExchangeBytes, "the exchange buffers set the LDS size");
     static_assert((5 * GW + 1) * 256 + BUF + 8 < 65536, "ds_read offsets are 16-bit");
 };
+
+// Packed fp32 arithmetic for the input transform: every value of the transform is a pair of channels in a register pair,
+// so one v_pk_* does what two v_fma_f32 / v_add_f32 would.  Measured beside back-to-back v_mfma_f32_16x16x4_f32 at three
+// waves per SIMD (tools/micro/mfma_f32_beside.hip): a v_fma_f32 takes 4.2 cycles from the matrix pipe, a v_pk_fma_f32 5.7.
+// ND_F4_PK=0 leaves the arithmetic to hipcc (which emits the scalar forms here).  Same bits either way (IEEE fma / add).
+#ifndef ND_F4_PK
+#define ND_F4_PK 1
+#endif
+typedef unsigned long long wf4_u64;
+#if ND_F4_PK
+#define ND_F4_FMA_C(NAME, CSTR)                                                                              \
+    __device__ __forceinline__ f32x2 NAME(f32x2 b, f32x2 a) { /* a + C * b */                                \
+        f32x2 r;                                                                                             \
+        asm("v_pk_fma_f32 %0, %1, " CSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(b), "v"(a));               \
+        return r;                                                                                            \
+    }
+#else
+#define ND_F4_FMA_C(NAME, CSTR) \
+    __device__ __forceinline__ f32x2 NAME(f32x2 b, f32x2 a) { return (float)(CSTR##f) * b + a; }
+#endif
+#if ND_F4_PK
+ND_F4_FMA_C(wf4_fma_p4, "4.0")
+ND_F4_FMA_C(wf4_fma_m4, "-4.0")
+ND_F4_FMA_C(wf4_fma_p2, "2.0")
+ND_F4_FMA_C(wf4_fma_m2, "-2.0")
+// a + s * b with the wave-uniform factor s in both halves of an SGPR pair
+__device__ __forceinline__ f32x2 wf4_fma_s(wf4_u64 s, f32x2 b, f32x2 a) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "s"(s), "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 wf4_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 wf4_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+__device__ __forceinline__ f32x2 wf4_fma_p4(f32x2 b, f32x2 a) { return 4.f * b + a; }
+__device__ __forceinline__ f32x2 wf4_fma_m4(f32x2 b, f32x2 a) { return -4.f * b + a; }
+__device__ __forceinline__ f32x2 wf4_fma_p2(f32x2 b, f32x2 a) { return 2.f * b + a; }
+__device__ __forceinline__ f32x2 wf4_fma_m2(f32x2 b, f32x2 a) { return -2.f * b + a; }
+__device__ __forceinline__ f32x2 wf4_fma_s(wf4_u64 s, f32x2 b, f32x2 a) { return __uint_as_float((unsigned)s) * b + a; }
+__device__ __forceinline__ f32x2 wf4_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 wf4_sub(f32x2 a, f32x2 b) { return a - b; }
+#endif
+__device__ __forceinline__ wf4_u64 wf4_pair(float f) {
+    const unsigned u = __float_as_uint(f);
+    return ((wf4_u64)u << 32) | u;
+}
 
 template <int I, int N, class F>
 __device__ __forceinline__ void wf4_sfor(F&& f) {
@@ -104,21 +158,22 @@ __global__ void __launch_bounds__(768, 3)
     __builtin_amdgcn_s_setprio(3);                                      // prologue and epilogue: no MFMAs, raised priority
     // Twelve waves = TWO half blocks of six (measured, tools/micro/mfma_f32_rate.hip: a 6-wave workgroup puts its waves on the
     // SIMDs as 2 + 2 + 1 + 1 and so does the next one on the same CU -- 0.73 of the MFMA rate; 12 waves are 3 + 3 + 3 + 3).
-    // The halves work on neighbouring m tiles of the same n block (the same weight fragments, so the second request hits in
-    // L1), each with its own halo buffers and its own half of the LDS; they share nothing but the workgroup barrier.
+    // The halves work on the SAME m tile and neighbouring n blocks (96 output channels per workgroup): ONE halo stream for
+    // both (an LDS-DMA instruction costs its wave 60-180 cycles of issue; shared, each wave issues half as many per chunk, and
+    // the input crosses L2 half as often); each half has its own weights, accumulators and its own half of the epilogue's LDS.
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vb = wv >= 6 ? 1 : 0;                                     // half block
     const int xi = wv - 6 * vb;                                         // wave = row of the 6x6 transform
-    float* const smem = smem_all + vb * (kWf4ExchangeBytes / 4);
+    float* const smem = smem_all;                                       // the two halo buffers (shared by the halves)
 
     const int total = gridDim.x;
     const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
     const int idp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     int mblk, nblk;
-    tile_of(idp, (p.mt + 1) >> 1, p.nt, p.ngroup, mblk, nblk);
-    mblk = mblk * 2 + vb;
-    const bool active = mblk < p.mt;          // odd tile count: the last half block recomputes the last tile and stores nothing
-    if (!active) mblk = p.mt - 1;
+    tile_of(idp, p.mt, (p.nt + 1) >> 1, p.ngroup, mblk, nblk);
+    nblk = nblk * 2 + vb;
+    const bool active = nblk < p.nt;          // odd number of n blocks: the last half block recomputes the last one and stores nothing
+    if (!active) nblk = p.nt - 1;
     const int bx = mblk % p.tiles_x;
     const int btmp = mblk / p.tiles_x;
     const int by = btmp % p.tiles_y;
@@ -132,12 +187,12 @@ __global__ void __launch_bounds__(768, 3)
         else return ((li & 3) << 2) | ((hyq & 1) << 1) | (gxq & 1);
     };
 
-    // ---- halo DMA descriptors: round k of wave xi fills the 64 16-byte units (k * 6 + xi) * 64 + lane
+    // ---- halo DMA descriptors: round k of wave wv fills the 64 16-byte units (k * 12 + wv) * 64 + lane
     constexpr unsigned kOOB = 0x80000000u;          // the host admits tensors of < 2 GiB
     unsigned vo[NDMA];
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-        const int U = (k * 6 + xi) * 64 + lane;
+        const int U = (k * 12 + wv) * 64 + lane;
         const int G = U >> 4, u = U & 15;
         const int gx = G % GW;
         const int gt = G / GW;
@@ -165,7 +220,7 @@ __global__ void __launch_bounds__(768, 3)
 #else
         const int che = ch < p.NC32 - 1 ? ch : p.NC32 - 1;
 #endif
-        auto* dst = (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(smem) + buf * BUF + (k * 6 + xi) * 1024);
+        auto* dst = (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(smem) + buf * BUF + (k * 12 + wv) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)vo[k], che * 64, 0, 0);
     };
 
@@ -179,8 +234,8 @@ __global__ void __launch_bounds__(768, 3)
         const int tli = t >> (THL2 + TWL2);
         const int tty = (t >> TWL2) & ((1 << THL2) - 1);
         const int ttx = t & ((1 << TWL2) - 1);
-        // (LDS byte addresses: the dynamic segment starts at 0, this half block's part at vb * kWf4ExchangeBytes)
-        const int G0 = ((tli * HH + 4 * tty) * GW + ttx + ((xi == 5) ? GW : 0)) * 256 + vb * kWf4ExchangeBytes;
+        // (LDS byte addresses: the dynamic segment starts at 0)
+        const int G0 = ((tli * HH + 4 * tty) * GW + ttx + ((xi == 5) ? GW : 0)) * 256;
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
             A00[cq] = G0 + ((((cq << 2) | kq) ^ key_of(tli, tty, ttx)) << 4);
@@ -214,27 +269,34 @@ __global__ void __launch_bounds__(768, 3)
     for (int nu = 0; nu < 6; ++nu)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[nu][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x3 wf[6];          // weight fragments of the current k4-step, re-loaded in place
+#if defined(ND_F4_LDX4)
+    typedef f32x4 wfrag_t;
+#else
+    typedef f32x3 wfrag_t;
+#endif
+    wfrag_t wf[6];        // weight fragments of the current k4-step, re-loaded in place
 #if defined(ND_F4ABL_NOB)
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) wf[nu] = f32x3{1.f, 0.5f, 0.25f};
+    for (int nu = 0; nu < 6; ++nu) { wf[nu][0] = 1.f; wf[nu][1] = 0.5f; wf[nu][2] = 0.25f; }
 #endif
     f32x2 v[6];           // transformed input of the current step (two k4-steps)
 
 #define ND_SB __builtin_amdgcn_sched_barrier(0)
 
-    auto ldfrag = [&](auto nuc, f32x3& d, const float* sbase) {
+    auto ldfrag = [&](auto nuc, wfrag_t& d, const float* sbase) {
         constexpr int off = decltype(nuc)::value * kWf4Frag * 4;
         const int vof = voff;             // (named outside the asm statement: clang does not capture a variable a generic lambda only uses as an asm operand)
-#if !defined(ND_F4ABL_NOB)
+#if defined(ND_F4_LDX4)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(vof), "s"(sbase), "i"(off));
+#elif !defined(ND_F4ABL_NOB)
         asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3" : "=v"(d) : "v"(vof), "s"(sbase), "i"(off));
 #else
         asm volatile("" : "+v"(d) : "v"(vof), "s"(sbase), "i"(off));
 #endif
     };
-    auto wait_vm = [&](auto nc, f32x3& d) {
+    auto wait_vm = [&](auto nc, wfrag_t& d) {
         constexpr int n = decltype(nc)::value;
-#if !defined(ND_F4ABL_NOB)
+#if !defined(ND_F4ABL_NOB) && !defined(ND_F4ABL_NOWAITVM)
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "i"(n));
 #else
         asm volatile("" : "+v"(d) : "i"(n));
@@ -252,8 +314,9 @@ __global__ void __launch_bounds__(768, 3)
 #define ND_IC(x) std::integral_constant<int, (x)>{}
 
     // transform coefficients of this wave's row: rows 1..4: t = (d4 + pc d2) + qc (d3 + pc d1); rows 0 / 5: t = 4 dA - 5 dB + dC
-    const float pc = (xi <= 2) ? -4.f : -1.f;
-    const float qc = (xi == 1) ? 1.f : ((xi == 2) ? -1.f : ((xi == 3) ? 2.f : -2.f));
+    const wf4_u64 pc = wf4_pair((xi <= 2) ? -4.f : -1.f);
+    const wf4_u64 qc = wf4_pair((xi == 1) ? 1.f : ((xi == 2) ? -1.f : ((xi == 3) ? 2.f : -2.f)));
+    const wf4_u64 m5 = wf4_pair(-5.f);
 
     // the whole main loop, instantiated for the two row types (a wave-uniform branch selects)
     auto run = [&](auto tac) {
@@ -283,23 +346,23 @@ __global__ void __launch_bounds__(768, 3)
             constexpr int c = decltype(cc)::value, n = decltype(nc)::value;
             f32x2* d = raw[c & 1];
             if constexpr (TA) {
-#if !defined(ND_F4ABL_NOA)
+#if !defined(ND_F4ABL_NOA) && !defined(ND_F4ABL_NOWAITLGKM)
                 asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "i"(n));
 #endif
 #if !defined(ND_F4ABL_NOT)
-                tt[c] = 4.f * d[0] + (-5.f * d[1] + d[2]);
+                tt[c] = wf4_fma_p4(d[0], wf4_fma_s(m5, d[1], d[2]));
 #else
                 tt[c] = d[0];
                 asm volatile("" :: "v"(d[1]), "v"(d[2]));
 #endif
             } else {
-#if !defined(ND_F4ABL_NOA)
+#if !defined(ND_F4ABL_NOA) && !defined(ND_F4ABL_NOWAITLGKM)
                 asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "i"(n));
 #endif
 #if !defined(ND_F4ABL_NOT)
-                const f32x2 a = pc * d[1] + d[3];
-                const f32x2 b = pc * d[0] + d[2];
-                tt[c] = qc * b + a;
+                const f32x2 a = wf4_fma_s(pc, d[1], d[3]);
+                const f32x2 b = wf4_fma_s(pc, d[0], d[2]);
+                tt[c] = wf4_fma_s(qc, b, a);
 #else
                 tt[c] = d[0];
                 asm volatile("" :: "v"(d[1]), "v"(d[2]), "v"(d[3]));
@@ -313,12 +376,12 @@ __global__ void __launch_bounds__(768, 3)
             v[k] = tt[k];
             return;
 #endif
-            if constexpr (k == 0) v[0] = 4.f * tt[0] + (-5.f * tt[2] + tt[4]);
-            if constexpr (k == 1) { ca = -4.f * tt[2] + tt[4]; cb = -4.f * tt[1] + tt[3]; v[1] = ca + cb; }
-            if constexpr (k == 2) v[2] = ca - cb;
-            if constexpr (k == 3) { ca = tt[4] - tt[2]; cb = tt[3] - tt[1]; v[3] = 2.f * cb + ca; }
-            if constexpr (k == 4) v[4] = -2.f * cb + ca;
-            if constexpr (k == 5) v[5] = 4.f * tt[1] + (-5.f * tt[3] + tt[5]);
+            if constexpr (k == 0) v[0] = wf4_fma_p4(tt[0], wf4_fma_s(m5, tt[2], tt[4]));
+            if constexpr (k == 1) { ca = wf4_fma_m4(tt[2], tt[4]); cb = wf4_fma_m4(tt[1], tt[3]); v[1] = wf4_add(ca, cb); }
+            if constexpr (k == 2) v[2] = wf4_sub(ca, cb);
+            if constexpr (k == 3) { ca = wf4_sub(tt[4], tt[2]); cb = wf4_sub(tt[3], tt[1]); v[3] = wf4_fma_p2(cb, ca); }
+            if constexpr (k == 4) v[4] = wf4_fma_m2(cb, ca);
+            if constexpr (k == 5) v[5] = wf4_fma_p4(tt[1], wf4_fma_s(m5, tt[3], tt[5]));
         };
 
         // ---- prologue: chunks 0 and 1, the fragments of k4-step 0, then the transform of chunk 0's first half
@@ -345,7 +408,9 @@ __global__ void __launch_bounds__(768, 3)
         auto step = [&](auto pcst, auto scst, int ch) {
             constexpr int P = decltype(pcst)::value, S = decltype(scst)::value;
             constexpr int RB = (S == 0) ? (P * BUF + 8) : ((1 - P) * BUF);
-#if defined(ND_F4ABL_BHIT)
+#if defined(ND_F4ABL_L1HIT)
+            const float* wcur = p.w;          // timing only: every wave of the chip reads the same 18 KiB (L1 hits)
+#elif defined(ND_F4ABL_BHIT)
             const float* wcur = wwave;        // timing only: the same fragments every chunk (cache hits)
 #else
             const float* wcur = wwave + (size_t)ch * cstride;
@@ -410,7 +475,7 @@ __global__ void __launch_bounds__(768, 3)
                  :
                  : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the halo buffers
-    f32x4* ex = reinterpret_cast<f32x4*>(smem);                      // [xi][b][ct][lane]
+    f32x4* ex = reinterpret_cast<f32x4*>(smem_all + vb * (kWf4ExchangeBytes / 4));          // this half's [xi][b][ct][lane]
     // M[xi][nu] -> r[b] = sum_nu At[b][nu] M[xi][nu], At = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -623,8 +688,8 @@ extern "C" const char* nd_conv_winograd_f4_variant_name(int variant) { return va
 
 extern "C" int nd_conv_winograd_f4_variant_info(int variant, int* bm, int* bn, int* threads) {
     if (variant != 0) return ND_E_ARG;
-    if (bm) *bm = 512;
-    if (bn) *bn = kWf4BN;
+    if (bm) *bm = 256;
+    if (bn) *bn = 2 * kWf4BN;
     if (threads) *threads = 768;
     return ND_OK;
 }
@@ -709,7 +774,8 @@ extern "C" int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, co
     a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TW - 1) / TW;
     a.mt = a.tiles_x * a.tiles_y * ((NI + NIB - 1) / NIB);
     a.nt = (N + kWf4BN - 1) / kWf4BN;
-    a.ngroup = pick_ngroup(a.nt, (size_t)kWf4BN * C0 * 36 * sizeof(float), (size_t)NI * (H >> up) * (W >> up) * C0 * sizeof(float));
+    // (the block -> tile order walks PAIRS of n blocks: tile_of's n axis is (nt + 1) / 2 long)
+    a.ngroup = pick_ngroup((a.nt + 1) / 2, (size_t)2 * kWf4BN * C0 * 36 * sizeof(float), (size_t)NI * (H >> up) * (W >> up) * C0 * sizeof(float));
     a.vec_ok = ((ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
                 (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
                 (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias)))) ? 1 : 0;
@@ -722,7 +788,7 @@ extern "C" int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, co
     a.mbi = (gw == 5) ? a.tiles_x * a.tiles_y : 1;
     if (chstats) ND_REQUIRE(ldo == N, fn, "output statistics need ldo == N");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int grid = ((a.mt + 1) / 2) * a.nt;          // a workgroup = two neighbouring m tiles of one n block
+    const int grid = a.mt * ((a.nt + 1) / 2);          // a workgroup = one m tile x two neighbouring n blocks
     const int rc = gw == 5 ? launch_wf4<5>(a, grid, s) : launch_wf4<3>(a, grid, s);
     if (rc != ND_OK || a.ksplit <= 1) return rc;
     return launch_splitk_reduce_f32(workspace, a.ksplit, a.ws_stride, (long)NI * H * W, N, bias, rowbias, ld_rowbias, H * W, residual,
