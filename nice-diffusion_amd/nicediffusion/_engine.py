@@ -805,6 +805,19 @@ class UNetPlan:
                         best, best_ms = ('wino+splitk', v4, S), ms
                 del ws
             del wq
+        if splitk_ok:
+            splits = (2, 4, 8)
+            ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, ksize, S), 4) for S in splits),
+                             dtype=torch.float32, device=self.device)
+            cands = [7, 8, 6, 5] + ([best[1]] if best[0] == 'direct' and best[1] < 9 and best[1] not in (7, 8, 6, 5) else [])
+            for v in cands:
+                for S in splits:
+                    ms = time_it(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v, S, ws.data_ptr()])
+                    if ms is not None:
+                        ms += pass_ms
+                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
+                        best, best_ms = ('direct+splitk', v, S), ms
+            del ws
         if f4_ok:
             # Winograd F(4x4,3x3): one pass, and -- where the m tiles do not fill the chip (16x16 and 8x8 maps at batch 64:
             # 384 / 128 workgroups for 256 CUs) -- split over K
@@ -823,19 +836,6 @@ class UNetPlan:
                         best, best_ms = ('wf4+splitk', 0, S), ms + pass_ms
                 del ws
             del wq
-        if splitk_ok:
-            splits = (2, 4, 8)
-            ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, ksize, S), 4) for S in splits),
-                             dtype=torch.float32, device=self.device)
-            cands = [7, 8, 6, 5] + ([best[1]] if best[0] == 'direct' and best[1] < 9 and best[1] not in (7, 8, 6, 5) else [])
-            for v in cands:
-                for S in splits:
-                    ms = time_it(self.lib.nd_conv_splitk_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v, S, ws.data_ptr()])
-                    if ms is not None:
-                        ms += pass_ms
-                    if ms is not None and (best_ms is None or ms < best_ms or (_f32_splitk() == 2 and not best[0].endswith('+splitk'))):
-                        best, best_ms = ('direct+splitk', v, S), ms
-            del ws
         del wp
         _TUNED[ck] = best
         return (best[0], (best[1], best[2])) if best[0].endswith('+splitk') else best

@@ -1058,3 +1058,157 @@ def test_groupnorm_coeffs_from_partials_equals_fold_then_coeffs(B, C0, C1, rows0
     assert (a1.view(B, C).cpu().double() - A).abs().max().item() < 1e-4 * A.abs().max().item()
     assert (b1.view(B, C).cpu().double() - Bc).abs().max().item() < 1e-4 * max(1.0, Bc.abs().max().item())
 
+
+
+# ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3)
+def pack_wf4(w):
+    N, C = w.shape[0], w.shape[1]
+    n = lib().nd_conv_winograd_f4_weight_floats(0, N, C)
+    assert n > 0
+    out = torch.full((n,), float('nan'), device=DEV)
+    _hip.check(lib().nd_repack_conv_weight_winograd_f4(w.contiguous().to(DEV).data_ptr(), out.data_ptr(), N, C, 0, st()))
+    return out
+
+
+def run_wf4(xd, Cin, ld, wd, bd, rbd, resd, ldr, B, H, W, N, flags=0, stats=None, splits=1, ws=None, ldo=None):
+    ldo = ldo or N
+    out = torch.full((B * H * W * ldo,), float('nan'), device=DEV)
+    rc = lib().nd_conv3x3_winograd_f4_nhwc(xd.data_ptr(), Cin, ld, wd.data_ptr(), None if bd is None else bd.data_ptr(),
+                                           None if rbd is None else rbd.data_ptr(), 0 if rbd is None else N,
+                                           None if resd is None else resd.data_ptr(), ldr, out.data_ptr(), ldo, B, H, W, N, flags, 0,
+                                           None if stats is None else stats.data_ptr(), splits, None if ws is None else ws.data_ptr(), st())
+    return rc, out
+
+
+# (B, Cin, Cout, H, W): the WINO_CASES whose maps are multiples of 4 (with Cin a whole number of 32-channel chunks), both block
+# geometries (16x16-pixel regions; four 8x8 images), partial regions (28x28, 12x20), N tails (52, 100, 6), odd numbers of
+# 48-channel n blocks, and the headline shapes at a small batch
+WF4_CASES = [(2, 32, 32, 16, 16), (1, 64, 96, 8, 8), (3, 32, 32, 28, 28), (2, 96, 6, 16, 16), (1, 192, 192, 64, 64), (5, 64, 64, 8, 8),
+             (3, 128, 52, 12, 20), (6, 64, 100, 8, 8), (2, 384, 384, 32, 32), (2, 576, 576, 16, 16), (5, 768, 768, 8, 8), (1, 64, 48, 40, 16)]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', WF4_CASES)
+def test_conv3x3_winograd_f4(B, Cin, Cout, H, W):
+    """conv_wf4_kernel (Winograd F(4x4,3x3), nd_conv3x3_winograd_f4_nhwc) vs a float64 conv2d: plain, with every fused option
+    (bias, per-image bias, residual, SiLU, 2x-upsampled input / residual), bitwise repeatable.  F(4x4,3x3) in fp32 carries
+    about 5x the rounding error of F(2x2,3x3); the bound is 4e-5 of the output's scale (measured 1.3e-5 ... 2.1e-5)."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    scale = ref.abs().max().item()
+    xd, wd, bd, rbd, resd = nhwc(x), pack_wf4(w), b.to(DEV), rb.to(DEV), nhwc(res)
+    rc, out = run_wf4(xd, Cin, Cin, wd, bd, None, None, 0, B, H, W, Cout)
+    assert rc == 0, _hip.last_error()
+    got = from_nhwc(out, B, H, W, Cout).double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 4e-5 * scale, (got - ref).abs().max().item() / scale
+    rc, out1 = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout)
+    assert rc == 0, _hip.last_error()
+    ref1 = ref + rb.double()[:, :, None, None] + res.double()
+    assert (from_nhwc(out1, B, H, W, Cout).double() - ref1).abs().max().item() < 4e-5 * scale
+    rc, out2 = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout)
+    assert rc == 0 and torch.equal(out1, out2)
+    rc, out3 = run_wf4(xd, Cin, Cin, wd, bd, None, None, 0, B, H, W, Cout, flags=_hip.CONV_SILU_OUT)
+    assert rc == 0, _hip.last_error()
+    assert (from_nhwc(out3, B, H, W, Cout).double() - F.silu(ref)).abs().max().item() < 4e-5 * scale
+    if H % 8 == 0 and W % 8 == 0 and H >= 16:
+        xs, rs = rnd(B, Cin, H // 2, W // 2, seed=7), rnd(B, Cout, H // 2, W // 2, seed=8)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+        refu = F.conv2d(up(xs).double(), w.double(), b.double(), padding=1) + up(rs).double()
+        rc, out4 = run_wf4(nhwc(xs), Cin, Cin, wd, bd, None, nhwc(rs), Cout, B, H, W, Cout,
+                           flags=_hip.CONV_IN_UP2X | _hip.CONV_RES_UP2X)
+        assert rc == 0, _hip.last_error()
+        assert (from_nhwc(out4, B, H, W, Cout).double() - refu).abs().max().item() < 4e-5 * max(scale, refu.abs().max().item())
+    # a padded output stride (ldo > N)
+    if Cout % 4 == 0:
+        rc, out5 = run_wf4(xd, Cin, Cin, wd, bd, None, None, 0, B, H, W, Cout, ldo=Cout + 8)
+        assert rc == 0, _hip.last_error()
+        assert torch.equal(out5.view(B, H, W, Cout + 8)[..., :Cout].contiguous().view(-1), out)
+
+
+def test_conv3x3_winograd_f4_refusals():
+    """What the F(4x4,3x3) entry point does not take is refused with a message (callers fall back to F(2x2,3x3) / direct)."""
+    x, w = rnd(2, 32, 16, 16, seed=1), rnd(48, 32, 3, 3, seed=2)
+    xd, wd = nhwc(x), pack_wf4(w)
+    out = torch.empty(2 * 16 * 16 * 48, device=DEV)
+
+    def call(Cin=32, H=16, W=16, flags=0, variant=0, splits=1, ws=None, stats=None, ldo=48):
+        return lib().nd_conv3x3_winograd_f4_nhwc(xd.data_ptr(), Cin, Cin, wd.data_ptr(), None, None, 0, None, 0, out.data_ptr(), ldo, 2, H, W,
+                                                 48, flags, variant, stats, splits, ws, st())
+    assert call(H=14, W=14) == -1 and 'multiples of 4' in _hip.last_error()
+    assert call(H=4, W=4) == -1
+    assert call(Cin=16) == -1 and '32-channel' in _hip.last_error()
+    assert call(variant=1) == -1
+    assert call(flags=_hip.CONV_GN_SILU) == -1 and 'flag' in _hip.last_error()
+    assert call(splits=2) == -1 and 'split-K' in _hip.last_error()
+    st_ = torch.empty(2 * 4 * 2 * 48, device=DEV)
+    assert call(stats=st_.data_ptr(), ldo=52) == -1 and 'ldo' in _hip.last_error()
+    assert lib().nd_conv_winograd_f4_stats_rows(0, 2, 14, 14) == 0 and lib().nd_conv_winograd_f4_stats_rows(0, 2, 64, 64) == 64
+    assert lib().nd_conv_winograd_f4_stats_rows(0, 2, 8, 8) == 4 and lib().nd_conv_winograd_f4_stats_rows(0, 2, 28, 28) == 16
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(3, 64, 192, 16, 16), (4, 32, 96, 8, 8), (2, 96, 40, 12, 20), (1, 32, 64, 64, 64), (2, 64, 144, 28, 28)])
+def test_conv_winograd_f4_epilogue_statistics(B, Cin, Cout, H, W):
+    """chstats of nd_conv3x3_winograd_f4_nhwc: same output as without, plus per-channel partial sums / sums of squares of that
+    output (one row per (m block, output column)), every entry written; nd_groupnorm_stats_from_partials folds them into what
+    the statistics kernel computes on the tensor."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    res = rnd(B, Cout, H, W, seed=4)
+    xd, wd, bd, rd = nhwc(x), pack_wf4(w), b.to(DEV), nhwc(res)
+    rows = lib().nd_conv_winograd_f4_stats_rows(0, B, H, W)
+    assert rows > 0
+    ps = torch.full((B * rows * 2 * Cout,), float('nan'), device=DEV)
+    rc, out = run_wf4(xd, Cin, Cin, wd, bd, None, rd, Cout, B, H, W, Cout, stats=ps)
+    assert rc == 0, _hip.last_error()
+    rc, plain = run_wf4(xd, Cin, Cin, wd, bd, None, rd, Cout, B, H, W, Cout)
+    assert rc == 0 and torch.equal(out, plain)
+    assert torch.isfinite(ps).all()                      # every partial row is written by every launch
+    got = from_nhwc(out, B, H, W, Cout).double()
+    c = ps.view(B, rows, 2, Cout).double().sum(1).cpu()      # [B][2][Cout]
+    assert (c[:, 0] - got.sum((2, 3))).abs().max().item() < 1e-3 * max(1.0, got.sum((2, 3)).abs().max().item())
+    assert ((c[:, 1] - (got ** 2).sum((2, 3))).abs() / (got ** 2).sum((2, 3))).max().item() < 1e-5
+    if Cout % 32 == 0:
+        a = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
+        b2 = gn_sums(*gn_stats(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, B, H * W), B).flatten().to(DEV)
+        assert ((a - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,S', [(16, 768, 768, 8, 8, 2), (16, 768, 768, 8, 8, 4), (4, 576, 576, 16, 16, 2), (2, 160, 96, 16, 16, 4),
+                                             (3, 96, 100, 8, 8, 2)])
+def test_conv3x3_winograd_f4_split_k(B, Cin, Cout, H, W, S):
+    """nd_conv3x3_winograd_f4_nhwc with splits > 1: block rows over ranges of 32-channel chunks + the deterministic reduce (bias,
+    per-image bias, residual applied there) vs float64 conv2d; bitwise repeatable; the workspace is written in full."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    rb, res = rnd(B, Cout, seed=5), rnd(B, Cout, H, W, seed=6)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + rb.double()[:, :, None, None] + res.double()
+    xd, wd, bd, rbd, resd = nhwc(x), pack_wf4(w), b.to(DEV), rb.to(DEV), nhwc(res)
+    need = lib().nd_conv_splitk_workspace_floats(B, H, W, Cout, Cin, 3, S)
+    assert need > 0
+    ws = torch.full((need,), float('nan'), device=DEV)
+    rc, out = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout, splits=S, ws=ws)
+    assert rc == 0, _hip.last_error()
+    assert torch.isfinite(ws).all()
+    got = from_nhwc(out, B, H, W, Cout).double()
+    assert (got - ref).abs().max().item() < 4e-5 * ref.abs().max().item()
+    rc, out2 = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout, splits=S, ws=ws)
+    assert rc == 0 and torch.equal(out, out2)
+
+
+def test_repack_conv_weight_winograd_f4():
+    """[chunk16][n block 48][xi][k4 step j][nu][lane][ct] = (G g G^T)[xi][nu] of output channel nblk*48 + ct*16 + (lane & 15) and input
+    channel chunk*16 + 4*(lane >> 4) + j, float64 rounded once; zero padded to whole blocks plus one chunk of read-ahead."""
+    N, C = 50, 32
+    w = rnd(N, C, 3, 3, seed=4)
+    out = pack_wf4(w).cpu()
+    nt, nc = (N + 47) // 48, C // 16 + 1
+    assert out.numel() == nc * nt * 6 * 4 * 6 * 64 * 3 == lib().nd_conv_winograd_f4_max_weight_read(0, N, C)
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                     dtype=torch.float64)
+    U = torch.einsum('ai,ncij,bj->ncab', G, w.double(), G)          # [N][C][6][6]
+    o = out.view(nc, nt, 6, 4, 6, 64, 3)
+    for (cq, nb, xi, j, nu, lane, ct) in [(0, 0, 0, 0, 0, 0, 0), (1, 1, 5, 3, 2, 17, 0), (0, 0, 3, 2, 4, 63, 2), (1, 0, 2, 1, 5, 40, 1), (0, 1, 4, 0, 1, 1, 0)]:
+        n, c = nb * 48 + ct * 16 + (lane & 15), cq * 16 + 4 * (lane >> 4) + j
+        want = U[n, c, xi, nu].float().item() if n < N else 0.0
+        assert o[cq, nb, xi, j, nu, lane, ct].item() == want, (cq, nb, xi, j, nu, lane, ct)
+    assert (o[nc - 1] == 0).all() and (o[:, 1, :, :, :, 2:16, 0] == 0).all()          # read-ahead chunk; channels >= N

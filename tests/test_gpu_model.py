@@ -622,17 +622,36 @@ def test_full_size_config2_plan_vs_reference_rows_and_oracle(golden_dir):
     so = DO.SamplerOracle(lambda a, b_, c: UO.unet_forward(sd, cfg, a, b_, c), DO.Schedule(1000, 250, 'cosine'),
                           'learned_interpolation', use_ddim=True, ddim_eta=0.0)
     assert (step[orow].cpu() - so.ddim_step(x[orow], first, y[orow])[0]).abs().max().item() < 1e-4
+    # (e) the chain is pinned at more than its first index (tests/golden/config2_headline_steps.npz, tools/gen_golden.py
+    # gen_config2_steps): teacher-forced steps at rescaled indices 125, 1 and 0 -- the middle of the chain, the low-noise
+    # coefficients and the t = 0 step whose noise term is masked (diffusion.py:365-366) -- with x_t from the reference's own
+    # Diffusion.diffuse for the three rows (the other rows of the batch take this build's diffuse: rows are independent)
+    gs = np.load(os.path.join(golden_dir, 'config2_headline_steps.npz'))
+    assert list(gs['rows']) == list(g['rows'])
+    errs_i = {}
+    for i in (int(v) for v in gs['indices']):
+        xt = d.diffuse(torch.tanh(x).to(DEV), steps_to_do=i + 1).cpu()
+        xt[rows] = torch.from_numpy(gs['xt_%d' % i])
+        st_i = d.denoise(x=xt, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=1, first_index=i, progress=False)
+        errs_i[i] = float(np.abs(st_i[rows].cpu().numpy() - gs['step_%d' % i]).max())
+        assert errs_i[i] < 1e-4, errs_i                         # measured 1e-5 ... 2e-5 with Winograd F(4x4,3x3) on every 3x3 layer
     a = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     b = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     assert torch.isfinite(a).all() and torch.equal(a, b)
-    print('config2 B=64 plan: forward rows vs reference {:.2e}, vs oracle {:.2e}; DDIM step vs reference {:.2e}'.format(
-        err, err_o, err_s))
+    print('config2 B=64 plan: forward rows vs reference {:.2e}, vs oracle {:.2e}; DDIM step vs reference {:.2e}; steps at 125 / 1 / 0 {}'.format(
+        err, err_o, err_s, ['%.2e' % errs_i[i] for i in (125, 1, 0)]))
+    kinds = [m_['variant'][0] for m_ in m._plan(64).meta if m_.get('variant') and m_.get('ksize') == 3]
+    print('3x3 launches by kernel family:', {k: kinds.count(k) for k in sorted(set(kinds))})
 
 
-def test_preset_64_own_25_step_ddim_chain_vs_reference(golden_dir):
+@pytest.mark.parametrize('f4', ['tuned', 'everywhere', 'off'])
+def test_preset_64_own_25_step_ddim_chain_vs_reference(golden_dir, f4, monkeypatch):
     """The 64x64 preset's OWN sampling configuration (default_args.py:15-21: 25-step DDIM, eta 0, cosine), free-running at
     B=2 from x_T to x_0 through Diffusion.denoise (hipGraph replay), vs the REAL reference's trajectory after 1 / 5 / 13 / 25
-    steps on the same weights (sigma_zero = 0.005: contractive), x_T and labels."""
+    steps on the same weights (sigma_zero = 0.005: contractive), x_T and labels.  Three plans: what the tuner picks at this
+    batch, Winograd F(4x4,3x3) FORCED onto every 3x3 layer that takes it (ND_WINOGRAD_F4=2: the numerically loosest plan this
+    build can run; profiles/r05_f4_numerics_preset64.txt predicts 1.4e-4 after 25 steps) and F(2x2,3x3) only."""
+    monkeypatch.setenv('ND_WINOGRAD_F4', {'tuned': '1', 'everywhere': '2', 'off': '0'}[f4])
     g = np.load(os.path.join(golden_dir, 'config2_headline_rows.npz'))
     m = build(dict(DA.OPENAI_64_MODEL_ARGS))
     d = Diffusion(model=m, **dict(DA.OPENAI_64_DIFFUSION_ARGS), device=DEV)
@@ -647,9 +666,17 @@ def test_preset_64_own_25_step_ddim_chain_vs_reference(golden_dir):
     d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=2, progress=False, trace=tr)       # eager, with the trajectory
     assert len(tr) == 25
     errs = [float(np.abs(tr[int(k)].cpu().numpy() - g['chain_traj'][i]).max()) for i, k in enumerate(g['chain_keep'])]
-    assert max(errs) < 1e-3 and max(errs) < 2e-4, errs          # measured 1.9e-6 / 1.2e-5 / 2.8e-5 / 3.7e-5
+    # measured: F(2x2) only 1.9e-6 / 1.2e-5 / 2.8e-5 / 3.7e-5; F(4x4) everywhere: see the printed line (bound = 2 x measured)
+    # F(4x4) everywhere 6.6e-6 / 3.3e-5 / 7.7e-5 / 1.12e-4 (72 of 74 launches); tuned at B=2 (19 of 74) 2.8e-6 / 1.7e-5 / 4.2e-5 / 6.0e-5
+    assert max(errs) < 1e-3 and max(errs) < (6e-5 if f4 == 'off' else 2.3e-4), errs
     assert torch.equal(tr[-1], out)
-    print('64x64 preset, 25-step DDIM free-running vs reference after 1/5/13/25 steps:', ['%.2e' % e for e in errs])
+    kinds = [m_['variant'][0] for m_ in m._plan(2).meta if m_.get('variant') and m_.get('ksize') == 3]
+    if f4 == 'everywhere':
+        assert kinds.count('wf4') >= 70, kinds
+    if f4 == 'off':
+        assert 'wf4' not in kinds
+    print('64x64 preset, 25-step DDIM free-running vs reference after 1/5/13/25 steps [F(4x4) {}: {} of {} 3x3 launches]:'.format(
+        f4, kinds.count('wf4'), len(kinds)), ['%.2e' % e for e in errs])
 
 
 @pytest.mark.parametrize('name,pname,B,cfg', [('config4', 'OPENAI_128', 16, True), ('config5', 'OPENAI_256', 16, False)])

@@ -200,11 +200,12 @@ def test_convert_state_dict_whole_preset_key_tables(golden_dir):
 
 
 def test_hand_scheduled_kernels_have_no_scratch_and_fit_two_waves_per_simd():
-    """gemm4_kernel, gemm_bf16q_kernel and conv_wino4_kernel issue their run-ahead loads as inline ISA whose destination
-    registers are "in flight" until a hand-counted s_waitcnt: a spill or a copy of such a register by a future compiler /
-    flag change would read it before the data has landed (the pattern behind the run-to-run race fixed in round 3).  The
-    built library's own metadata must show no scratch, no spills and <= 256 VGPRs (two blocks of 4 waves per CU) for
-    every instantiation of the three kernels."""
+    """gemm4_kernel, gemm_bf16q_kernel, conv_wino4_kernel and conv_wf4_kernel issue their run-ahead loads as inline ISA whose
+    destination registers are "in flight" until a hand-counted s_waitcnt: a spill or a copy of such a register by a future
+    compiler / flag change would read it before the data has landed (the pattern behind the run-to-run race fixed in round
+    3).  The built library's own metadata must show no scratch, no spills and <= 256 VGPRs (two blocks of 4 waves per CU)
+    for every instantiation of the first three and <= 168 (three waves per SIMD: one 12-wave workgroup per CU)
+    for conv_wf4_kernel."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location('kernel_regs', os.path.join(root, 'tools', 'kernel_regs.py'))
@@ -214,12 +215,24 @@ def test_hand_scheduled_kernels_have_no_scratch_and_fit_two_waves_per_simd():
     assert len(tab) > 100
     seen = set()
     for name, r in tab.items():
-        for k in ('gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel'):
+        for k in ('gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel', 'conv_wf4_kernel'):
             if 'nd::' + k in name:
                 seen.add(k)
                 assert r['scratch'] == 0 and r['sgpr_spill'] == 0 and r['vgpr_spill'] == 0, (name, r)
-                assert r['vgpr'] + r['agpr'] <= 256, (name, r)
-    assert seen == {'gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel'}, seen
+                assert r['vgpr'] + r['agpr'] <= (168 if k == 'conv_wf4_kernel' else 256), (name, r)
+    assert seen == {'gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel', 'conv_wf4_kernel'}, seen
+
+
+def test_conv_wf4_lds_halo_image_is_what_the_reads_expect():
+    """conv_wf4_kernel fills its halo buffers by LDS-DMA (one 16-byte unit per lane and round, a 4-bit XOR key per 4-pixel group)
+    and reads them back with per-lane addresses built from four keys: tools/wf4_lds_image.py restates both index maps and checks
+    every (tile, patch element, k group) of both block geometries against the unit the DMA put there."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'wf4_lds_image.py')], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count('image consistent') == 2 and 'False' not in out.stdout, out.stdout
 
 
 def test_bench_weights_are_the_survey_recipe_the_parity_tests_use():
@@ -255,6 +268,8 @@ def test_committed_tune_caches_match_the_built_library():
             elif kind in ('wino', 'wino+splitk'):
                 assert 0 <= var < lib.nd_conv_winograd_num_variants() and \
                     not lib.nd_conv_winograd_variant_name(var).startswith(b'(retired)')
+            elif kind in ('wf4', 'wf4+splitk'):
+                assert 0 <= var < lib.nd_conv_winograd_f4_num_variants(), (k, v)
             else:
                 assert kind in ('direct', 'direct+splitk') and 0 <= var < lib.nd_conv_num_variants(), (k, v)
         saved = dict(_engine._TUNED)
@@ -330,6 +345,10 @@ def test_weight_read_ahead_stays_inside_the_packed_tensors():
             for v in range(-1, lib.nd_conv_winograd_num_variants()):
                 r = lib.nd_conv_winograd_max_weight_read(v, N, C)
                 assert 0 < r <= size, ('wino', v, N, C, r, size)
+            for v in range(lib.nd_conv_winograd_f4_num_variants()):
+                size = lib.nd_conv_winograd_f4_weight_floats(v, N, C)
+                r = lib.nd_conv_winograd_f4_max_weight_read(v, N, C)
+                assert 0 < r <= size, ('wf4', v, N, C, r, size)
     # the bound is tight where it matters: the two-fragments-per-chunk 1x1 stream of the 16x16x32 layout needs both padding chunks
     names = [lib.nd_conv_bf16_variant_name(v) for v in range(lib.nd_conv_bf16_num_variants())]
     vs = [v for v, n in enumerate(names) if n == b'nd::conv_bf16s_kernel']

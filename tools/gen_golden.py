@@ -327,6 +327,38 @@ def gen_config2():
          ddim_step=step.numpy(), chain_keep=np.array(keep), chain_traj=torch.stack(traj).numpy())
 
 
+def gen_config2_steps():
+    """BASELINE configs[1]'s chain pinned at MORE than its first index: teacher-forced DDIM steps of the 250-step cosine
+    chain at rescaled indices 125, 1 and 0 (the middle of the chain, the low-noise coefficients, and the t = 0 step whose
+    noise term is masked, diffusion.py:365-366) for rows 0 / 31 / 63 of the B=64 batch.  x_t comes from the reference's own
+    Diffusion.diffuse (diffusion.py:133-153) of a clean image x_0 = tanh(x) with stored noise; the rows of x_t are stored so
+    that the test feeds the B=64 plan exactly what the reference saw."""
+    cfg = dict(ref_presets.OPENAI_64_MODEL_ARGS)
+    sd = UO.synth_state_dict(cfg, seed=1234)
+    m = ref_model(cfg, sd)
+    torch.manual_seed(0)
+    x = torch.randn(64, 3, 64, 64)
+    y = (torch.arange(64) * 37) % 1000
+    idx = torch.tensor(HEADLINE_ROWS)
+    x0, yr = torch.tanh(x[idx]), y[idx]
+    nz = torch.randn(len(idx), 3, 64, 64, generator=torch.Generator().manual_seed(77))
+    d = Diffusion(m, 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='cosine', use_ddim=True, ddim_eta=0.0,
+                  device=torch.device('cpu'))
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, 250, 'cosine'),
+                          'learned_interpolation', use_ddim=True, ddim_eta=0.0)
+    arrs = dict(rows=np.array(HEADLINE_ROWS), indices=np.array([125, 1, 0]))
+    for i in (125, 1, 0):
+        xt = d.diffuse(x0, steps_to_do=i + 1, noise=nz)
+        with torch.no_grad():
+            step, _ = d.ddim_denoising_step(xt, i * torch.ones(len(idx)), {'y': yr})
+        e = (so.ddim_step(xt, i, yr)[0] - step).abs().max().item()
+        print('   config2 rows DDIM step at index', i, 'oracle-vs-reference', e, 'absmax', step.abs().max().item())
+        assert e < 5e-5
+        arrs['xt_%d' % i] = xt.numpy()
+        arrs['step_%d' % i] = step.numpy()
+    save('config2_headline_steps.npz', **arrs)
+
+
 def gen_large_rows():
     """Two rows of the full-batch forwards of BASELINE configs[3] (128x128 preset + null class, 2B = 32 forwards per step,
     second half = the null class) and configs[4] (256x256 preset, B = 16) through the REAL reference in fp32.  Stored as a
@@ -425,8 +457,8 @@ def gen_embed():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse', 'config2', 'large_rows']
-    fns = dict(diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
+    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse', 'config2', 'config2_steps', 'large_rows']
+    fns = dict(config2_steps=gen_config2_steps, diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
                samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets, config2=gen_config2,
                large_rows=gen_large_rows)
     for w in which:
