@@ -193,8 +193,12 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
             hb += rec['hbm_bytes']
             ab += alg
         if ab > 0:
+            from nicediffusion import _engine
+            stamps = tab.get('_stamps') or {}
             traffic = {'hbm_bytes_per_launch': hb / max(1, g['launches'] - missing), 'algorithmic_bytes_per_launch':
                        ab / max(1, g['launches'] - missing), 'ratio': round(hb / ab, 3), 'shapes_missing': missing,
+                       # the table is a lookup, not a measurement of this run: stale = it was taken on another library build
+                       'stale': _engine._tune_stamp() not in stamps.values(),
                        'source': 'profiles/{} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, keyed by the shapes '
                                  'launched)'.format(tab_name)}
     sec = g['ms'] * 1e-3
@@ -235,12 +239,12 @@ def class_breakdown(rows):
 def pick_cpu_threads(fn):
     """PyTorch's default thread count (the box's physical cores) is not the fastest for these small convolutions on a
     two-socket host: run ``fn`` (one small sampler step; also the warm-up of the thread pool and allocator) at the default
-    and at 1/2, 1/4, 1/8 of it, leave the fastest count set and return (it, the default, {count: seconds})."""
+    and at 1/2, 1/4, 1/8, 1/16 of it (never below 8), leave the fastest count set and return (it, the default, {count:
+    seconds}).  The fastest count uses a small part of a 256-CPU host: the line says how much (``host_cpus_used_frac``)."""
     default_threads = torch.get_num_threads()
     tried = {}
     fn()
-    for th in sorted({default_threads, max(8, default_threads // 2), max(8, default_threads // 4), max(8, default_threads // 8)},
-                     reverse=True):
+    for th in sorted({default_threads} | {max(8, default_threads // d) for d in (2, 4, 8, 16)}, reverse=True):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
         fn()
@@ -298,7 +302,8 @@ def cpu_baseline(model, margs, wl, batch=None, steps=2):
     torch.set_num_threads(default_threads)
     nfwd = batch * (2 if wl['cfg'] is not None else 1)
     return {'value': round(batch / (dt * wl['chain']), 6), 'unit': 'images/sec', 'cores': best_threads,
-            'kind': 'port', 'host_cpus': os.cpu_count(), 's_per_image_forward': round(dt / nfwd, 4),
+            'kind': 'port', 'host_cpus': os.cpu_count(), 'host_cpus_used_frac': round(best_threads / max(1, os.cpu_count() or 1), 3),
+            's_per_image_forward': round(dt / nfwd, 4),
             'step_s': [round(v, 2) for v in ts], 'threads_tried_s_per_batch{}_step'.format(nb): tried,
             'sample': '{} timed sampler step{} (UNet forward{} + update; small untimed steps before, which also pick the thread '
                       'count) at batch {} of the same {}x{} '

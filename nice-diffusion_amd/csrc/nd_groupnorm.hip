@@ -779,6 +779,7 @@ extern "C" int nd_groupnorm_fused_nhwc(const void* x0, int C0, int ldx0, const v
                (C0 + C1) % G == 0 && (C0 + C1) / G <= 64, fn, "bad arguments (channels per group <= 64)");
     ND_REQUIRE(ldx0 >= C0 && (C1 == 0 || (x1 && ldx1 >= C1)) && ldo >= C0 + C1, fn, "strides");
     ND_REQUIRE((scale == nullptr) == (shift == nullptr), fn, "scale and shift go together");
+    ND_REQUIRE(!scale || ld_ss >= C0 + C1, fn, "ld_ss < C0 + C1 (the AdaGN rows would be read past their end)");
     ND_REQUIRE((long)H * W * ((C0 + C1) / G) < (1L << 30), fn, "tensor too large for the one-launch form");
     const bool pool = (flags & ND_GN_POOL2) != 0;
     if (pool) ND_REQUIRE((H & 1) == 0 && (W & 1) == 0, fn, "POOL2 needs even H, W");

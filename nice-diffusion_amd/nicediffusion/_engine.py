@@ -39,7 +39,13 @@ def _tune_stamp():
     names = [lib.nd_conv_winograd_variant_name(v).decode() for v in range(lib.nd_conv_winograd_num_variants())]
     names += [lib.nd_conv_winograd_f4_variant_name(v).decode() for v in range(lib.nd_conv_winograd_f4_num_variants())]
     names += [lib.nd_conv_bf16_variant_name(v).decode() for v in range(lib.nd_conv_bf16_num_variants())]
-    return 'v{}:d{}:{}'.format(lib.nd_version(), lib.nd_conv_num_variants(), '|'.join(names))
+    # the direct / GEMM variants have no names: their block shapes identify them (a renumbered or retuned variant changes the stamp)
+    bm, bn, nt = (ctypes.c_int() for _ in range(3))
+    direct = []
+    for v in range(lib.nd_conv_num_variants()):
+        lib.nd_conv_variant_info(v, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
+        direct.append('{}x{}x{}'.format(bm.value, bn.value, nt.value))
+    return 'v{}:d{}:{}:{}'.format(lib.nd_version(), lib.nd_conv_num_variants(), ','.join(direct), '|'.join(names))
 
 
 def preload_tune_cache(path, device_index=None, override=False):

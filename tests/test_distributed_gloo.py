@@ -61,23 +61,24 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n', [4, 5])
-def test_sharded_denoise_matches_single_process(n):
+@pytest.mark.parametrize('n,world', [(4, 2), (5, 2), (8, 8), (11, 8)])
+def test_sharded_denoise_matches_single_process(n, world):
+    """world 2 and world 8 (north_star's node: 8 ranks, one per GPU; here 8 gloo ranks on the CPU), even and ragged shards"""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, full, g = q.get(timeout=300)
+    out, full, g = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     assert out.shape == full.shape
-    # rows are computed independently per sample: a 2-rank run reproduces the 1-process run row by row
+    # rows are computed independently per sample: an N-rank run reproduces the 1-process run row by row
     assert np.abs(out - full).max() < 1e-5
     from nicediffusion.parallel import shard_slice
-    exp = np.concatenate([np.full((shard_slice(n, r, 2).stop - shard_slice(n, r, 2).start, 2), float(r)) for r in (0, 1)])
+    exp = np.concatenate([np.full((shard_slice(n, r, world).stop - shard_slice(n, r, world).start, 2), float(r)) for r in range(world)])
     assert np.array_equal(g, exp)
 
 
@@ -115,6 +116,36 @@ def test_bench_multi_rank_branch_over_gloo():
     assert rk['chain_ms']['max'] >= rk['chain_ms']['min'] >= 0 and rk['all_gather_ms']['max'] > 0
     assert rk['distinct_devices'] == 1            # both stub ranks report the host's 'cpu': ranks sharing a device are SEEN
     assert rec['config']['unet_forwards_per_sampler_step'] == 1 and rec['config']['images_through_the_unet_per_sampler_step'] == 5
+
+
+@pytest.mark.parametrize('workload,batch,gbatch,cfgname', [('config2', 64, 512, 'configs[2]'), ('config5', 16, 128, 'configs[4]')])
+def test_bench_eight_rank_branch_over_gloo(workload, batch, gbatch, cfgname):
+    """The driver's SCALE run shape rehearsed on the CPU: bench.py --gpus 8 with WORLD_SIZE=8 over gloo, the denoiser stubbed out
+    (ND_BENCH_STUB=1: no GPU work) -- BASELINE configs[2] (global batch 512 = 64 per rank) and configs[4] (128 = 16 per rank):
+    rows per rank, gather order, the process group's own world size, whole-job images over the MAX-reduced time."""
+    import json
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, WORLD_SIZE='8', RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), ND_BENCH_BACKEND='gloo', ND_BENCH_STUB='1', OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2',
+                                       '--warmup', '1', '--workload', workload], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    assert not any(l.startswith('{') for o in outs[1:] for l in o[0].splitlines()), 'only rank 0 prints the JSON line'
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['steps'] == 2 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == gbatch and rec['config']['per_gpu_batch'] == batch
+    assert abs(rec['value'] - gbatch * 2 / (rec['ms_per_step'] * 2e-3)) / rec['value'] < 0.02
+    rk = rec['ranks']
+    assert rk['process_group'] == {'backend': 'gloo', 'world_size': 8}
+    assert [r['rank'] for r in rk['per_rank']] == list(range(8))
+    assert [r['rows'] for r in rk['per_rank']] == [[batch * r, batch * (r + 1)] for r in range(8)]
 
 
 def _tune_worker(rank, world, port, tmp, q):

@@ -792,6 +792,11 @@ def test_groupnorm_fused_one_launch(B, C0, C1, H, W, mode, dtype):
     if H % 2:
         assert lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), None, None, 0,
                                              out.data_ptr(), C, B, H, W, 32, 1e-5, _hip.GN_POOL2, dt, st()) != 0
+    # AdaGN rows shorter than the channel count would be read past their end: refused like nd_groupnorm_apply_nhwc's strides
+    if sc is not None:
+        assert lib().nd_groupnorm_fused_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, gd.data_ptr(), bd.data_ptr(), p(sc), p(sh), C - 4,
+                                             out.data_ptr(), C, B, H, W, 32, 1e-5, flags & ~_hip.GN_POOL2, dt, st()) != 0
+        assert 'ld_ss' in _hip.last_error()
 
 
 @pytest.mark.parametrize('ratio', [1.0, 10.0, 30.0])

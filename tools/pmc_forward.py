@@ -38,7 +38,8 @@ while time.time() - t0 < 1.5:
     torch.cuda.synchronize()
 out = os.path.join(ROOT, 'gpurun_out', 'pmc_ops_{}.json'.format(wl_name))
 os.makedirs(os.path.dirname(out), exist_ok=True)
-json.dump({'workload': wl_name, 'NI': NI, 'reps': reps, 'dtype': wl['dtype'], 'ops': plan.meta}, open(out, 'w'))
+from nicediffusion import _engine  # noqa: E402
+json.dump({'workload': wl_name, 'NI': NI, 'reps': reps, 'dtype': wl['dtype'], 'ops': plan.meta, 'stamp': _engine._tune_stamp()}, open(out, 'w'))
 torch.cuda.synchronize()
 for _ in range(reps):
     plan.run()

@@ -19,14 +19,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FNS = ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv_bf16_nhwc', 'nd_conv3x3_winograd_stats_nhwc',
             'nd_conv3x3_winograd_vstats_nhwc', 'nd_conv3x3_bf16_stats_nhwc', 'nd_conv1x1_bf16_stats_nhwc', 'nd_conv_bf16_splitk_nhwc',
-            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc')
-CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel',
+            'nd_conv_splitk_nhwc', 'nd_conv3x3_winograd_splitk_nhwc', 'nd_conv1x1_stats_nhwc', 'nd_conv3x3_winograd_f4_nhwc')
+CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', 'conv_wf4_kernel', 'conv_mfma_kernel',
                 'gemm_stream_kernel', 'conv_bf16_kernel', 'conv_bf16s_kernel', 'gemm_bf16_kernel', 'gemm_bf16q_kernel', 'gemm_f32_kernel',
                 'gemm4_kernel')
 # the other kernel classes of a forward: counters aggregated per kernel name (no per-shape key)
 CLASS_KERNELS = ('attention_kernel', 'attention_bf16_kernel', 'gn_stats_kernel', 'gn_apply_kernel', 'gn_from_partials_kernel',
                  'gn_coeffs_kernel', 'gn_coeffs_from_partials_kernel', 'gn_fused_small_kernel', 'splitk_reduce_kernel', 'splitk_reduce_f32_kernel')
-OUT_NAME = os.environ.get('ND_PMC_OUT', os.environ.get('ROUND', 'r04') + '_pmc_shapes.json')
+OUT_NAME = os.environ.get('ND_PMC_OUT', os.environ.get('ROUND', 'r05') + '_pmc_shapes.json')
 
 
 def dispatches(d, kernels=CONV_KERNELS):
@@ -158,6 +158,8 @@ def main():
     merged['_totals_' + wl] = {k: dict(hbm_bytes_per_forward=int(v[0]), algorithmic_bytes_per_forward=int(v[1]),
                                        ratio=round(v[0] / v[1], 3), launches=v[2]) for k, v in by_kernel.items()}
     merged['_classes_' + wl] = cls_out
+    # which library build the counters belong to (bench.py flags a table taken on another build as stale)
+    merged.setdefault('_stamps', {})[wl] = ops.get('stamp')
     merged['_comment'] = ('Generated by tools/pmc_shapes.sh (rocprofv3 --pmc passes over tools/pmc_forward.py, separate passes for '
                           'FETCH_SIZE / WRITE_SIZE / SQ counters) and tools/pmc_shapes.py; key = kind:variant:k<ksize>:NI:H:W:Cin:N of a '
                           'conv launch IN the forward; hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x '
