@@ -121,10 +121,13 @@ __device__ __forceinline__ void wf4_sfor(F&& f) {
 
 // VMEM operations younger than the fragment load of slot i - 6 when slot i of a step starts (5 fragment loads + the halo
 // DMAs of step 1, which sit in slots 0 .. NDMA - 1 in front of the slot's load)
+#ifndef ND_F4_LDEARLY
+#define ND_F4_LDEARLY 1      // a slot's fragment load is issued right behind its MFMAs, in front of the slot's transform work and DMA: +1.3..2.3 % (0: behind them)
+#endif
 constexpr int wf4_younger(int S, int i, int NDMA) {
     int y = 5;
     if (S == 1)
-        for (int k = (i - 5 > 0 ? i - 5 : 0); k <= i - 1; ++k)
+        for (int k = (i - 5 - ND_F4_LDEARLY > 0 ? i - 5 - ND_F4_LDEARLY : 0); k <= i - 1; ++k)
             if (k < NDMA) ++y;
     return y;
 }
@@ -399,7 +402,14 @@ __global__ void __launch_bounds__(768, 3)
             (void)c;
         });
         wf4_sfor<0, 6>([&](auto kc) { col_part(kc); });
+#if !defined(ND_F4_NOPRIO_B)
+        __builtin_amdgcn_s_setprio(TA ? 0 : 1);          // the rows with the longer transform run ahead of rows 0 / 5: +1.7..2.3 %, interleaved A/B
+#elif defined(ND_F4_PRIO_VB)
+        if (vb) __builtin_amdgcn_s_setprio(1);           // experiment: one half block ahead of the other
+        else __builtin_amdgcn_s_setprio(0);
+#else
         __builtin_amdgcn_s_setprio(0);
+#endif
 
         // one step = two k4-steps of chunk ch (S = 0: channels 0..7, S = 1: 8..15), 36 MFMAs in 12 slots of one position each.
         // Under them: the patch reads and the transform of the NEXT step (S = 0: this chunk's second half, S = 1: the next
@@ -425,13 +435,19 @@ __global__ void __launch_bounds__(768, 3)
                 for (int ct = 0; ct < CT; ++ct)
                     acc[nu][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nu][ct], v[nu][jj], acc[nu][ct], 0, 0, 0);
                 ND_SB;
+#if ND_F4_LDEARLY
+                ldfrag(ND_IC(nu), wf[nu], jj == 0 ? wn0 : wn1);
+                ND_SB;
+#endif
                 if constexpr (i >= 2 && i <= 7) row_col(ND_IC(i - 2), ND_IC(i == 7 ? 0 : NR));
                 if constexpr (i < 6) issue_col(ND_IC(i), ND_IC(RB));
                 if constexpr (i >= 7) col_part(ND_IC(i - 7));
                 if constexpr (S == 1 && i < NDMA) halo_issue(i, ch + 2, P);
                 ND_SB;
+#if !ND_F4_LDEARLY
                 ldfrag(ND_IC(nu), wf[nu], jj == 0 ? wn0 : wn1);
                 ND_SB;
+#endif
             });
             col_part(ND_IC(5));
             ND_SB;
@@ -439,7 +455,7 @@ __global__ void __launch_bounds__(768, 3)
                 // every read of this chunk's buffer has returned; chunk ch + 1 (issued a chunk ago, in front of 25 - NDMA younger
                 // operations) has landed.  Behind the barrier the buffer of chunk ch is free for chunk ch + 2.
 #if !defined(ND_F4ABL_NOBAR)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(25 - NDMA) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(25 - NDMA - ND_F4_LDEARLY) : "memory");
                 __builtin_amdgcn_s_barrier();
 #endif
             }
