@@ -181,7 +181,9 @@ int nd_conv3x3_winograd_nhwc(const float* x0, int C0, int ldx0, const float* x1,
  * chstats | NULL: per-channel partial statistics of the output, [NI][rows][sum | sum of squares][N] fp32 with
  *   rows = nd_conv_winograd_f4_stats_rows(variant, NI, H, W) per image, every entry written by every launch (needs ldo == N);
  *   nd_groupnorm_stats_from_partials folds them.
- * splits > 1: split over K as nd_conv3x3_winograd_splitk_nhwc (same workspace size, same restrictions; no chstats). */
+ * splits > 1: split over K as nd_conv3x3_winograd_splitk_nhwc (same workspace size, same restrictions); chstats then come from
+ *   the reduce pass, nd_conv_winograd_f4_splitk_stats_rows rows per image (one per run of 16 pixels; 0: H * W % 16 != 0 and such a
+ *   launch takes no chstats). */
 int nd_conv_winograd_f4_num_variants(void);
 const char* nd_conv_winograd_f4_variant_name(int variant);
 int nd_conv_winograd_f4_variant_info(int variant, int* bm, int* bn, int* threads);
@@ -189,6 +191,7 @@ int64_t nd_conv_winograd_f4_weight_floats(int variant, int N, int C);
 int64_t nd_conv_winograd_f4_max_weight_read(int variant, int N, int C);
 int nd_repack_conv_weight_winograd_f4(const float* w_oihw, float* w_out, int N, int C, int variant, nd_stream_t stream);
 int nd_conv_winograd_f4_stats_rows(int variant, int NI, int H, int W);
+int nd_conv_winograd_f4_splitk_stats_rows(int variant, int NI, int H, int W);
 int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, const float* w, const float* bias,
                                 const float* rowbias, int ld_rowbias, const float* residual, int ldr, float* out, int ldo,
                                 int NI, int H, int W, int N, int flags, int variant, float* chstats, int splits,

@@ -147,6 +147,11 @@ static inline int splitk_plan_f32(int C, int ksize, int splits, int* kchunks) {
 // second pass of a split launch (nd_conv_mfma.hip): out = sum_s ws[s] + bias + rowbias[img] + residual, SiLU last
 int launch_splitk_reduce_f32(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
                              int ld_rowbias, int hw, const float* res, int ldr, float* out, int ldo, int silu, hipStream_t s);
+// the same + per-channel partial statistics of the output, one row per run of kSplitkStatsPixels pixels of an image (hw must be
+// a multiple of it, N of 4): chstats [NI][hw / kSplitkStatsPixels][sum | sum of squares][N]
+constexpr int kSplitkStatsPixels = 16;
+int launch_splitk_reduce_stats_f32(const float* ws, int S, long ws_stride, int NI, int hw, int N, const float* bias, const float* rowbias,
+                                   int ld_rowbias, const float* res, int ldr, float* out, int ldo, int silu, float* chstats, hipStream_t s);
 
 struct TilePlan {
     int thl, twl, nibl, tiles_x, tiles_y, groups, hp;

@@ -431,6 +431,75 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The same reduction that also leaves the per-channel partial statistics of what it stores behind (the layout the
+// convolutions' epilogues write: chstats [NI][hw / kSplitkStatsPixels][sum | sum of squares][N], fp32, every entry written):
+// one block per run of kSplitkStatsPixels pixels of an image, one thread per 4 channels walking the run, so a thread's sums ARE
+// the row -- no cross-thread step, a fixed order.  A layer run split over K keeps its output statistics this way instead of
+// costing the norms that read it a pass over the tensor (round 5: the 16x16 layers of configs[1] on conv_wf4_kernel).
+__global__ void __launch_bounds__(256)
+    splitk_reduce_stats_f32_kernel(const float* ws, int S, long ws_stride, int hw, int N, const float* bias, const float* rowbias,
+                                   int ld_rowbias, const float* res, int ldr, float* out, int ldo, int silu, float* chstats) {
+    const int rpi = hw / kSplitkStatsPixels;          // rows (= blocks) per image
+    const int img = blockIdx.x / rpi, rb = blockIdx.x - img * rpi;
+    const long m0 = (long)img * hw + (long)rb * kSplitkStatsPixels;
+    for (int n = threadIdx.x << 2; n < N; n += blockDim.x << 2) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+        if (rowbias) {
+            const f32x4 rbv = *reinterpret_cast<const f32x4*>(rowbias + (size_t)img * ld_rowbias + n);
+            // (the association of splitk_reduce_f32_kernel: ((sum + bias) + rowbias) + residual)
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int i = 0; i < kSplitkStatsPixels; ++i) {
+                const long m = m0 + i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+                for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (size_t)s * ws_stride + m * N + n);
+                if (bias) v += bv;
+                v += rbv;
+                if (res) v += *reinterpret_cast<const f32x4*>(res + m * ldr + n);
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(out + m * ldo + n) = v;
+                ssum += v;
+                ssq += v * v;
+            }
+            float* ps = chstats + (((size_t)img * rpi + rb) * 2) * N + n;
+            *reinterpret_cast<f32x4*>(ps) = ssum;
+            *reinterpret_cast<f32x4*>(ps + N) = ssq;
+        } else {
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int i = 0; i < kSplitkStatsPixels; ++i) {
+                const long m = m0 + i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+                for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(ws + (size_t)s * ws_stride + m * N + n);
+                if (bias) v += bv;
+                if (res) v += *reinterpret_cast<const f32x4*>(res + m * ldr + n);
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(out + m * ldo + n) = v;
+                ssum += v;
+                ssq += v * v;
+            }
+            float* ps = chstats + (((size_t)img * rpi + rb) * 2) * N + n;
+            *reinterpret_cast<f32x4*>(ps) = ssum;
+            *reinterpret_cast<f32x4*>(ps + N) = ssq;
+        }
+    }
+}
+
+int launch_splitk_reduce_stats_f32(const float* ws, int S, long ws_stride, int NI, int hw, int N, const float* bias, const float* rowbias,
+                                   int ld_rowbias, const float* res, int ldr, float* out, int ldo, int silu, float* chstats, hipStream_t s) {
+    const int threads = (N >> 2) >= 256 ? 256 : (((N >> 2) + 63) / 64) * 64;
+    hipLaunchKernelGGL(splitk_reduce_stats_f32_kernel, dim3(NI * (hw / kSplitkStatsPixels)), dim3(threads), 0, s, ws, S, ws_stride, hw, N,
+                       bias, rowbias, ld_rowbias, res, ldr, out, ldo, silu, chstats);
+    return check_launch("split-K reduce + statistics");
+}
+
 int launch_splitk_reduce_f32(const float* ws, int S, long ws_stride, long M, int N, const float* bias, const float* rowbias,
                              int ld_rowbias, int hw, const float* res, int ldr, float* out, int ldo, int silu, hipStream_t s) {
     const long quads = M * (N >> 2);

@@ -743,6 +743,14 @@ extern "C" int nd_conv_winograd_f4_stats_rows(int variant, int NI, int H, int W)
     return gw == 5 ? ((W + 15) / 16) * ((H + 15) / 16) * 4 : 4;
 }
 
+// the same for a launch split over K: the rows come from the reduce pass, one per run of 16 pixels of an image (0: the map's
+// pixel count is not a multiple of 16 -- such a launch cannot take chstats)
+extern "C" int nd_conv_winograd_f4_splitk_stats_rows(int variant, int NI, int H, int W) {
+    if (variant != 0 || NI <= 0) return ND_E_ARG;
+    if (wf4_geometry(H, W) == 0 || ((long)H * W) % kSplitkStatsPixels) return 0;
+    return (int)(((long)H * W) / kSplitkStatsPixels);
+}
+
 extern "C" int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, const float* w, const float* bias,
                                            const float* rowbias, int ld_rowbias, const float* residual, int ldr, float* out,
                                            int ldo, int NI, int H, int W, int N, int flags, int variant, float* chstats, int splits,
@@ -767,8 +775,9 @@ extern "C" int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, co
     ConvArgs a{};
     a.ksplit = 1; a.kchunks = 0; a.ws_stride = 0;
     if (splits > 1) {
-        ND_REQUIRE(splits <= 16 && workspace != nullptr && aligned16(workspace) && chstats == nullptr, fn,
-                   "split-K: 2..16 splits, a 16-byte aligned workspace, no output statistics");
+        ND_REQUIRE(splits <= 16 && workspace != nullptr && aligned16(workspace), fn, "split-K: 2..16 splits, a 16-byte aligned workspace");
+        if (chstats) ND_REQUIRE(((long)H * W) % kSplitkStatsPixels == 0 && aligned16(chstats), fn,
+                                "split-K with output statistics: H * W must be a multiple of 16");
         ND_REQUIRE(!(flags & ND_CONV_RES_UP2X) && (N & 3) == 0 && (ldo & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
                    (!residual || ((ldr & 3) == 0 && aligned16(residual))) &&
                    (!rowbias || ((ld_rowbias & 3) == 0 && aligned16(rowbias))), fn,
@@ -800,13 +809,16 @@ extern "C" int nd_conv3x3_winograd_f4_nhwc(const float* x0, int C0, int ldx0, co
         a.bias = nullptr; a.rowbias = nullptr; a.res = nullptr; a.out = workspace; a.ldo = N; a.silu_out = 0; a.res_up = 0;
         a.vec_ok = 1;
     }
-    a.chstats = chstats;
+    a.chstats = (a.ksplit > 1) ? nullptr : chstats;          // split over K: the reduce pass writes them
     a.mbi = (gw == 5) ? a.tiles_x * a.tiles_y : 1;
     if (chstats) ND_REQUIRE(ldo == N, fn, "output statistics need ldo == N");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = a.mt * ((a.nt + 1) / 2);          // a workgroup = one m tile x two neighbouring n blocks
     const int rc = gw == 5 ? launch_wf4<5>(a, grid, s) : launch_wf4<3>(a, grid, s);
     if (rc != ND_OK || a.ksplit <= 1) return rc;
+    if (chstats)
+        return launch_splitk_reduce_stats_f32(workspace, a.ksplit, a.ws_stride, NI, H * W, N, bias, rowbias, ld_rowbias, residual, ldr, out, ldo,
+                                              (flags & ND_CONV_SILU_OUT) ? 1 : 0, chstats, s);
     return launch_splitk_reduce_f32(workspace, a.ksplit, a.ws_stride, (long)NI * H * W, N, bias, rowbias, ld_rowbias, H * W, residual,
                                     ldr, out, ldo, (flags & ND_CONV_SILU_OUT) ? 1 : 0, s);
 }

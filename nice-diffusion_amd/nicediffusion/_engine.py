@@ -403,8 +403,9 @@ class UNetPlan:
                     raise _hip.NdHipError('nd_conv_splitk_workspace_floats: ' + _hip.last_error())
                 self._splitk_floats = max(self._splitk_floats, need)
                 ws = ('splitk', 0)
-            elif stats_wanted:
-                rows = self.lib.nd_conv_winograd_f4_stats_rows(0, NI, H, W)
+            if stats_wanted:
+                # per-channel partial statistics of the output: from the kernel's epilogue, or -- split over K -- from the reduce pass
+                rows = (self.lib.nd_conv_winograd_f4_splitk_stats_rows if splits > 1 else self.lib.nd_conv_winograd_f4_stats_rows)(0, NI, H, W)
                 if rows > 0:
                     ph = ('chpart', self._cs_floats)
                     out.cs = (ph, rows)
@@ -830,17 +831,24 @@ class UNetPlan:
             wq = self._packed_wf4(weight, pad_c_to)
             f4_args = head[:3] + [wq.data_ptr()] + tail + [flags, 0]
             force = _winograd_f4() == 2 and not best[0].startswith('wf4')
-            ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None, 1, None])
+            rows1 = self.lib.nd_conv_winograd_f4_stats_rows(0, NI, H, W) if stats_wanted else 0
+            sbuf1 = torch.empty(NI * rows1 * 2 * N, dtype=torch.float32, device=self.device) if rows1 > 0 else None
+            ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None if sbuf1 is None else sbuf1.data_ptr(), 1, None])
+            del sbuf1
             if ms is not None and (best_ms is None or ms < best_ms or force):
                 best, best_ms = ('wf4', 0), ms
             if _f32_splitk() and NI * H * W <= 32768 and C >= 256 and N % 4 == 0 and not (flags & _hip.CONV_RES_UP2X):
                 ws = torch.empty(max(max(self.lib.nd_conv_splitk_workspace_floats(NI, H, W, N, C, 3, S), 4) for S in (2, 4)),
                                  dtype=torch.float32, device=self.device)
+                # (with statistics wanted the reduce pass writes them where the map allows: timed that way, no pass to add)
+                srows = self.lib.nd_conv_winograd_f4_splitk_stats_rows(0, NI, H, W) if stats_wanted else 0
+                sbuf = torch.empty(NI * srows * 2 * N, dtype=torch.float32, device=self.device) if srows > 0 else None
+                extra = 0.0 if srows > 0 else pass_ms
                 for S in (2, 4):
-                    ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None, S, ws.data_ptr()])
-                    if ms is not None and (best_ms is None or ms + pass_ms < best_ms):
-                        best, best_ms = ('wf4+splitk', 0, S), ms + pass_ms
-                del ws
+                    ms = time_it(self.lib.nd_conv3x3_winograd_f4_nhwc, f4_args + [None if sbuf is None else sbuf.data_ptr(), S, ws.data_ptr()])
+                    if ms is not None and (best_ms is None or ms + extra < best_ms):
+                        best, best_ms = ('wf4+splitk', 0, S), ms + extra
+                del ws, sbuf
             del wq
         del wp
         _TUNED[ck] = best

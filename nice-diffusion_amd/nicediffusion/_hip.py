@@ -46,6 +46,7 @@ SIGNATURES = {
     'nd_conv3x3_winograd_f4_nhwc': [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     'nd_repack_conv_weight_winograd_f4': [_vp, _vp, _i, _i, _i, _vp],
     'nd_conv_winograd_f4_stats_rows': [_i, _i, _i, _i],
+    'nd_conv_winograd_f4_splitk_stats_rows': [_i, _i, _i, _i],
     'nd_groupnorm_stats_from_partials': [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     'nd_conv3x3_winograd_stats_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                        _i, _i, _i, _i, _i, _vp, _vp],

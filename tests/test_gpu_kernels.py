@@ -1146,6 +1146,7 @@ def test_conv3x3_winograd_f4_refusals():
     assert call(variant=1) == -1
     assert call(flags=_hip.CONV_GN_SILU) == -1 and 'flag' in _hip.last_error()
     assert call(splits=2) == -1 and 'split-K' in _hip.last_error()
+    assert lib().nd_conv_winograd_f4_splitk_stats_rows(0, 2, 16, 16) == 16 and lib().nd_conv_winograd_f4_splitk_stats_rows(0, 2, 14, 14) == 0
     st_ = torch.empty(2 * 4 * 2 * 48, device=DEV)
     assert call(stats=st_.data_ptr(), ldo=52) == -1 and 'ldo' in _hip.last_error()
     assert lib().nd_conv_winograd_f4_stats_rows(0, 2, 14, 14) == 0 and lib().nd_conv_winograd_f4_stats_rows(0, 2, 64, 64) == 64
@@ -1198,6 +1199,22 @@ def test_conv3x3_winograd_f4_split_k(B, Cin, Cout, H, W, S):
     assert (got - ref).abs().max().item() < 4e-5 * ref.abs().max().item()
     rc, out2 = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout, splits=S, ws=ws)
     assert rc == 0 and torch.equal(out, out2)
+    # output statistics of a split launch come from the reduce pass: one row per run of 16 pixels of an image, same output bits
+    rows = lib().nd_conv_winograd_f4_splitk_stats_rows(0, B, H, W)
+    assert rows == H * W // 16
+    ps = torch.full((B * rows * 2 * Cout,), float('nan'), device=DEV)
+    rc, out3 = run_wf4(xd, Cin, Cin, wd, bd, rbd, resd, Cout, B, H, W, Cout, splits=S, ws=ws, stats=ps)
+    assert rc == 0, _hip.last_error()
+    assert torch.equal(out3, out) and torch.isfinite(ps).all()
+    c = ps.view(B, rows, 2, Cout).double().sum(1).cpu()
+    assert (c[:, 0] - got.sum((2, 3))).abs().max().item() < 1e-3 * max(1.0, got.sum((2, 3)).abs().max().item())
+    assert ((c[:, 1] - (got ** 2).sum((2, 3))).abs() / (got ** 2).sum((2, 3))).max().item() < 1e-5
+    if Cout % 32 == 0:
+        a = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
+        _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), Cout, rows, None, 0, 0, a.data_ptr(), B, 32, st()))
+        b2 = gn_sums(*gn_stats(out.data_ptr(), Cout, Cout, None, 0, 0, None, 0, B, H * W), B).flatten().to(DEV)
+        # (fp32 rows of 16 pixels each, |y| up to 5: measured 1.8e-5 of max(|sum|, 1) on a group whose first moment cancels)
+        assert ((a - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 5e-5
 
 
 def test_repack_conv_weight_winograd_f4():

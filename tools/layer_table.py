@@ -5,22 +5,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nice-diffusion_amd')); sys.path.insert(0, ROOT)
 import torch
 import bench
+CONV = bench.CONV_FNS
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+from nicediffusion import _engine
+_engine.preload_tune_cache(os.path.join(ROOT, 'profiles', 'tune_cache_config2.json'), override=True)
 margs, model, diff = bench.build(torch.device('cuda'))
 plan, rows = bench.kernel_breakdown(model, B, reps=3)
 tot = sum(r['ms'] for r in rows)
 print('forward %.2f ms, %.1f TFLOP/s' % (tot, plan.flops / tot / 1e9))
 agg = {}
 for r in rows:
-    if r['fn'] in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv3x3_winograd_vstats_nhwc') and r['shape']:
+    if r['fn'] in CONV and r['shape']:
         k = (r['ksize'],) + tuple(r['shape']) + (r['variant'],)
         a = agg.setdefault(k, [0, 0.0, 0])
         a[0] += 1; a[1] += r['ms']; a[2] += r['flops']
 print('%-4s %-26s %-3s %5s %9s %8s %7s' % ('k', 'NI,H,W,Cin,N', 'var', 'calls', 'ms_total', 'ms_avg', 'TF/s'))
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print('%-4d %-26s %-10s %5d %9.3f %8.3f %7.1f' % (k[0], ','.join(map(str, k[1:6])), '%s%d' % (k[6][0][0], k[6][1]), a[0], a[1], a[1] / a[0], a[2] / a[1] / 1e9))
+    print('%-4d %-26s %-10s %5d %9.3f %8.3f %7.1f' % (k[0], ','.join(map(str, k[1:6])), '%s%d' % (k[6][0][:4], k[6][1]), a[0], a[1], a[1] / a[0], a[2] / a[1] / 1e9))
 oth = {}
 for r in rows:
-    if r['fn'] not in ('nd_conv_nhwc', 'nd_conv3x3_winograd_nhwc', 'nd_conv3x3_winograd_vstats_nhwc'):
+    if r['fn'] not in CONV or not r['shape']:
         oth[r['fn']] = oth.get(r['fn'], 0) + r['ms']
 print({k: round(v, 3) for k, v in oth.items()})
