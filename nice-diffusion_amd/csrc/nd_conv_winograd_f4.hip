@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(768, 3)
     const unsigned npix = (unsigned)(p.NI * p.Hs * p.Ws);
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x0) + cshift, 0,
                                                                         (int)(npix * (unsigned)p.ldx0 * 4u) - cshift * 4, 0x00020000);
-    // one DMA round of chunk ch; chunks past the last one re-fetch the last chunk into a buffer nobody reads, so that the number
-    // of VMEM operations per chunk is a constant the hand-counted waits can rely on
+    // one DMA round of chunk ch; chunks past the last one are still ISSUED -- the number of VMEM operations per chunk is a constant
+    // the hand-counted waits rely on -- but with every lane out of range: zeros into a buffer nobody reads, no memory traffic
     auto halo_issue = [&](int k, int ch, int buf) {
 #if defined(ND_F4ABL_NOHALO)
         return;
@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(768, 3)
         const int che = ch < p.NC32 - 1 ? ch : p.NC32 - 1;
 #endif
         auto* dst = (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(smem) + buf * BUF + (k * 12 + wv) * 1024);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, (int)vo[k], che * 64, 0, 0);
+        const int vof = ch < p.NC32 ? (int)vo[k] : (int)kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, vof, che * 64, 0, 0);
     };
 
     // ---- patch read addresses.  Lane = (tile t = lane & 15, k group kq = lane >> 4): element (r, c) of the tile's 6x6 patch,
@@ -566,7 +567,11 @@ __global__ void __launch_bounds__(768, 3)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] = fast_silu(o[c]);
                         }
+#if defined(ND_F4ABL_NOSTORE)
+                        if (o[0] == 123.456f) *reinterpret_cast<f32x4*>(op) = o;          // timing only
+#else
                         *reinterpret_cast<f32x4*>(op) = o;
+#endif
                         if constexpr (STATS) {
                             ssum += o;
                             ssq += o * o;
