@@ -175,7 +175,7 @@ def roofline_from(rows, lib, dtype='fp32', esize=4):
             'v_mfma_f32_16x16x32_bf16' if lib.nd_conv_bf16_variant_layout(max(var, 0)) else 'v_mfma_f32_32x32x16_bf16')
     else:
         lib.nd_conv_variant_info(var, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
-        base = 'nd::conv_mfma_kernel' if var < 9 else ('nd::gemm_stream_kernel' if var < 13 else 'nd::gemm_f32_kernel')
+        base = 'nd::conv_mfma_kernel' if var < 9 else ('nd::gemm_stream_kernel' if var < 13 else ('nd::gemm_f32_kernel' if var == 13 else 'nd::gemm4_kernel'))
         kname = '{}<{}x{} tile, {} threads, {} taps>'.format(base, bm.value, bn.value, nt.value, ksize * ksize)
     # HBM traffic of this kernel over the forward: counter bytes of every shape it ran on / algorithmic bytes
     traffic = None

@@ -204,7 +204,16 @@ int launch_wino4(const ConvArgs& a, int grid, size_t lds, hipStream_t s);
 // gemm_f32_kernel (nd_gemm_f32.hip), launched by nd_conv_nhwc's variant 13
 int launch_gemm_f32(const ConvArgs& a, int grid, hipStream_t s);
 // gemm4_kernel (nd_gemm_f32_quad.hip), launched by nd_conv_nhwc's variant 14
-int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s);
+int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s, int tm = 4);
+// 256- or 128-pixel blocks for gemm4_kernel (variants 14 / 15 of nd_conv_nhwc) where no caller measured: the smaller tile where
+// it fills the chip's block slots (512 at two 256-pixel blocks per CU, 768 at three 128-pixel ones) better -- rounds of blocks
+// are what a short GEMM pays for
+static inline int gemm4_pick_tm(long M, int nt) {
+    if (M % 256) return 2;
+    const long b4 = M / 256 * nt, b2 = M / 128 * nt;
+    const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512), e2 = (double)b2 / (double)(((b2 + 767) / 768) * 768);
+    return e2 > e4 + 0.04 ? 2 : 4;
+}
 
 static inline int ilog2(int v) {
     int l = 0;

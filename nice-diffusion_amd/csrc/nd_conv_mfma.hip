@@ -745,6 +745,7 @@ static const Variant kVariants[] = {
     // GEMM form, two blocks per CU (gemm4_kernel, nd_gemm_f32_quad.hip): pixel rows by buffer_load lds, no vector
     // instruction per DMA, hand-counted waits
     {2, 2, 4, 2, 2},   // 14: 256 x 128, 4 waves
+    {2, 2, 2, 2, 3},   // 15: 128 x 128, 4 waves, three blocks per CU: the same kernel where 256-pixel tiles fill the chip badly
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static constexpr int kFirstStream = 9;
@@ -880,7 +881,7 @@ extern "C" int64_t nd_conv_max_weight_read(int variant, int N, int C, int ksize)
     for (int v = 0; v < kNumVariants; ++v) {
         if (variant >= 0 && v != variant) continue;
         const int a = v < kFirstStream ? wstream::f32_conv_ahead(taps)
-                                       : (v < 13 ? wstream::kF32StreamAhead : (v == 13 ? wstream::kF32GemmAhead : wstream::kF32Gemm4Ahead));
+                                       : (v < 13 ? wstream::kF32StreamAhead : (v == 13 ? wstream::kF32GemmAhead : wstream::kF32Gemm4Ahead));          // 14, 15: gemm4_kernel
         ahead = a > ahead ? a : ahead;
     }
     return (int64_t)(nc32_padded(C) + wstream::pad_chunks(ahead, taps * 4)) * nt32 * taps * 4 * 256;
@@ -978,7 +979,7 @@ static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, cons
     a.vec_ok = 0; a.nhi = 0; a.zero = nullptr; a.chstats = nullptr; a.mbi = 1;
     if (chstats) {
         // output statistics: gemm4_kernel only (variant 14), one fp32 row per (image, 128-pixel run)
-        ND_REQUIRE(best_v == 14 && flat && gnA == nullptr && splits <= 1, fn, "output statistics: the two-blocks-per-CU GEMM (variant 14) only, no fused GroupNorm");
+        ND_REQUIRE((best_v == 14 || best_v == 15) && flat && gnA == nullptr && splits <= 1, fn, "output statistics: the two-blocks-per-CU GEMM (variants 14 / 15) only, no fused GroupNorm");
         ND_REQUIRE(((long)H * W) % 128 == 0 && (N & 3) == 0 && ldo == N && aligned16(out) && aligned16(chstats) &&
                    (!bias || aligned16(bias)) && (!residual || ((ldr & 3) == 0 && aligned16(residual))), fn,
                    "output statistics: H*W % 128 == 0, N % 4 == 0, ldo == N, 16-byte aligned rows");
@@ -1009,12 +1010,13 @@ static int conv_f32_impl(const char* fn, const float* x0, int C0, int ldx0, cons
             a.zero = w + (nd_conv_weight_floats(N, C0 + C1, ksize) - 4);      // 16 bytes of the packed weights' zero padding chunk
             return launch_gemm_f32(a, grid, s);
         case 14:
+        case 15:
             // gemm4_kernel addresses its input through buffer descriptors with the row advance in the scalar offset
-            ND_REQUIRE(M % 256 == 0, fn, "the two-blocks-per-CU GEMM needs a multiple of 256 pixels");
+            ND_REQUIRE(M % (best_v == 14 ? 256 : 128) == 0, fn, "the two-blocks-per-CU GEMM needs a multiple of 256 (variant 15: 128) pixels");
             ND_REQUIRE(((C0 + C1) & 31) == 0 && (C1 == 0 || (C0 & 31) == 0), fn, "the two-blocks-per-CU GEMM needs whole 32-channel chunks");
             ND_REQUIRE(M * ldx0 * 4 < (1L << 31) && (C1 == 0 || M * ldx1 * 4 < (1L << 31)), fn,
                        "the two-blocks-per-CU GEMM needs input tensors of less than 2 GiB");
-            return launch_gemm4(a, grid, s);
+            return launch_gemm4(a, grid, s, best_v == 14 ? 4 : 2);
     }
     const int rc = (taps == 9) ? dispatch<9>(best_v, a, grid, lds, s) : dispatch<1>(best_v, a, grid, lds, s);
     if (rc != ND_OK || a.ksplit <= 1) return rc;
@@ -1046,7 +1048,9 @@ extern "C" int nd_conv1x1_stats_nhwc(const float* x0, int C0, int ldx0, const fl
                                      int NI, int H, int W, int N, int flags, float* chstats, nd_stream_t stream) {
     const char* fn = "nd_conv1x1_stats_nhwc";
     ND_REQUIRE(chstats != nullptr, fn, "chstats is null");
-    return conv_f32_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, nullptr, 0, residual, ldr, out, ldo, NI, H, W, N, 1, flags, 14,
+    // 256- or 128-pixel blocks: whichever fills the chip's block slots better (rows of 128 pixels either way)
+    const int v = (NI > 0 && H > 0 && W > 0 && N > 0 && gemm4_pick_tm((long)NI * H * W, (N + 127) / 128) == 2) ? 15 : 14;
+    return conv_f32_impl(fn, x0, C0, ldx0, x1, C1, ldx1, w, bias, nullptr, 0, residual, ldr, out, ldo, NI, H, W, N, 1, flags, v,
                          nullptr, nullptr, 0, stream, 1, nullptr, chstats);
 }
 

@@ -11,19 +11,22 @@
 //   * operand loads are inline ISA with hand-counted vmcnt / lgkmcnt (hipcc parks every LDS read behind all pending
 //     LDS-DMA otherwise), everything for k-step s + 1 is requested at the top of k-step s.
 // Block = 256 pixels x 128 channels (2 x 2 waves, wave tile 4 x 2 MFMA tiles = 8 accumulators), K in 32-channel chunks
-// through two LDS stages at 0 and 32 KiB (the stage is one address bit).  The host requires M % 256 == 0, whole
+// through two LDS stages at 0 and 32 KiB (the stage is one address bit).  TM = 2 is the same kernel on 128 pixels x 128
+// channels (wave tile 2 x 2): the launcher takes it where the 256-pixel tiles fill the chip's 512 block slots badly and the
+// 128-pixel ones do not (32x32 x 384 -> 1152 at batch 64: 2304 blocks = 4.5 rounds against 4608 = 9; -> 384: 1.5 against 3).  The host requires M % 256 == 0, whole
 // 32-channel chunks on either side of a concatenation seam and tensors < 2 GiB (32-bit buffer offsets); with a fused
 // GroupNorm also H * W % 256 == 0 (one image per block).
 #include "nd_conv_common.h"
 
 namespace nd {
 
-template <bool GN, bool STATS = false>          // STATS: also leave the per-channel partial statistics of the output behind (p.chstats)
+template <bool GN, bool STATS = false, int TM = 4>          // STATS: also leave the per-channel partial statistics of the output behind (p.chstats)
 __global__ void __launch_bounds__(256, 2)
     gemm4_kernel(const ConvArgs p) {
-    constexpr int BM = 256, BN = 128, TM = 4, TN = 2;
-    constexpr int STAGE_B = 32768;                     // bytes between the two stages (a stage holds 256 rows x 128 bytes)
-    constexpr int NDMA = 8;                            // DMA rounds per wave and chunk: 8 x 4 waves x 1 KiB = 32 KiB
+    static_assert(TM == 4 || TM == 2, "256- or 128-pixel blocks");
+    constexpr int BM = 64 * TM, BN = 128, TN = 2;
+    constexpr int STAGE_B = 32768;                     // bytes between the two stages (a stage holds up to 256 rows x 128 bytes)
+    constexpr int NDMA = 2 * TM;                       // DMA rounds per wave and chunk: 8 x 4 waves x 1 KiB = 32 KiB (TM = 2: 4, 16 KiB)
     constexpr int LPS = GN ? 4 : 2;                    // register loads per k-step: 2 weight fragments (+ 2 coefficient vectors)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -66,14 +69,16 @@ __global__ void __launch_bounds__(256, 2)
     };
 
     // ---- fragment reads: row = (wm * 4 + mi) * 32 + l31 (same swizzle for the four mi), slot (kc << 1 | lh) ^ swz
-    const int arow = wm * 128 + l31;
+    const int arow = wm * (TM * 32) + l31;
     const int aoff = arow * 128 + ((lh ^ ((arow >> 1) & 7)) << 4);          // bytes, k-step 0, stage 0; mi adds 4096 per tile
     auto rdA = [&](f32x4 (&a)[TM], int sbits) {          // sbits = stage bit | (kc << 5): one v_xor, four reads
         const int addr = aoff ^ sbits;
         asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(addr));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(addr));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(addr));
-        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(addr));
+        if constexpr (TM == 4) {
+            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(addr));
+            asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(addr));
+        }
     };
     // ---- weight fragments [c32][n tile][kc][lane][4]: scalar base + lane * 16; the wave's two n tiles are 4 KiB apart
     int nt0 = nblk * 4 + wn * 2, nt1 = nt0 + 1;
@@ -119,7 +124,7 @@ __global__ void __launch_bounds__(256, 2)
     auto wait_vm = [&](f32x4& r0, f32x4& r1, int n) {
 #define ND_G4CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" : "+v"(r0), "+v"(r1)); break;
         switch (n) {
-            ND_G4CASE(2) ND_G4CASE(4) ND_G4CASE(6) ND_G4CASE(10) ND_G4CASE(12)
+            ND_G4CASE(2) ND_G4CASE(4) ND_G4CASE(6) ND_G4CASE(8) ND_G4CASE(10) ND_G4CASE(12)
             default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)); break;
         }
 #undef ND_G4CASE
@@ -135,8 +140,13 @@ __global__ void __launch_bounds__(256, 2)
             a = v;
         }
     };
-    auto wait_lds4 = [&](f32x4 (&a)[TM]) {          // the four reads of THIS k-step have returned; the four just issued may be in flight
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    auto wait_lds4 = [&](f32x4 (&a)[TM]) {          // the TM reads of THIS k-step have returned; the TM just issued may be in flight
+        if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[0]), "+v"(a[1]));
+    };
+    auto wait_lds0 = [&](f32x4 (&a)[TM]) {
+        if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]));
     };
 
     f32x16 acc[TM][TN];
@@ -158,13 +168,13 @@ __global__ void __launch_bounds__(256, 2)
     ldB(bfr[0], 0, 0);
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) dma(k, 1, 1);
-    if constexpr (GN) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // chunk 0 has landed: LPS + 8 younger operations
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS + NDMA) : "memory");          // chunk 0 has landed: LPS + NDMA younger operations
     __builtin_amdgcn_s_barrier();
     rdA(afr[0], 0);
     if constexpr (GN) {
-        asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)"          // the coefficients of k-step 0: 2 weight loads + 8 DMA rounds are younger
-                     : "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3]), "+v"(cfr[0][0]), "+v"(cfr[0][1]));
+        asm volatile("s_waitcnt vmcnt(%2)"          // the coefficients of k-step 0: 2 weight loads + NDMA rounds are younger
+                     : "+v"(cfr[0][0]), "+v"(cfr[0][1]) : "i"(2 + NDMA));
+        wait_lds0(afr[0]);
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) fold(afr[0][mi], cfr[0]);
     }
@@ -196,9 +206,9 @@ __global__ void __launch_bounds__(256, 2)
                     // the NEXT k-step's fragments are normalised under this k-step's second half of MFMAs: they and their
                     // coefficients were requested at the top; behind the coefficients only the 2 weight loads (and, in
                     // k-step 3, the DMA rounds issued so far: 2 per mi) are younger
-                    if (mi == 2) {
-                        wait_vm(cfr[nxt][0], cfr[nxt][1], 2 + (st == 3 ? 2 * TN : 0));
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afr[nxt][0]), "+v"(afr[nxt][1]), "+v"(afr[nxt][2]), "+v"(afr[nxt][3]));
+                    if (mi == TM / 2) {
+                        wait_vm(cfr[nxt][0], cfr[nxt][1], 2 + (st == 3 ? (TM / 2) * TN : 0));
+                        wait_lds0(afr[nxt]);
                     }
                 }
 #pragma unroll
@@ -208,7 +218,7 @@ __global__ void __launch_bounds__(256, 2)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cur][ni][j], afr[cur][mi][j], acc[mi][ni], 0, 0, 0);
                         if (st == 3 && j == 1) dma(mi * 2 + ni, ch + 2, dstage);          // 8 rounds over the k-step's 32 MFMAs
                         if constexpr (GN) {
-                            if (mi >= 2 && j == 3) fold(afr[nxt][(mi - 2) * 2 + ni], cfr[nxt]);      // one fragment per 4 MFMAs
+                            if (mi >= TM / 2 && j == 3) fold(afr[nxt][(mi - TM / 2) * 2 + ni], cfr[nxt]);      // one fragment per 4 MFMAs
                         }
                         ND_SB;
                     }
@@ -224,12 +234,19 @@ __global__ void __launch_bounds__(256, 2)
     }
 #undef ND_SB
     // the run-ahead loads of the last k-step are still in flight: keep their registers allocated until they have returned
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(cfr[0][0]), "+v"(cfr[0][1]),
-                   "+v"(cfr[1][0]), "+v"(cfr[1][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3]),
-                   "+v"(afr[1][0]), "+v"(afr[1][1]), "+v"(afr[1][2]), "+v"(afr[1][3])
-                 :
-                 : "memory");
+    if constexpr (TM == 4)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(cfr[0][0]), "+v"(cfr[0][1]),
+                       "+v"(cfr[1][0]), "+v"(cfr[1][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][TM - 2]), "+v"(afr[0][TM - 1]),
+                       "+v"(afr[1][0]), "+v"(afr[1][1]), "+v"(afr[1][TM - 2]), "+v"(afr[1][TM - 1])
+                     :
+                     : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(cfr[0][0]), "+v"(cfr[0][1]),
+                       "+v"(cfr[1][0]), "+v"(cfr[1][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[1][0]), "+v"(afr[1][1])
+                     :
+                     : "memory");
     __builtin_amdgcn_s_setprio(3);
 
     // ---- epilogue: lane = one pixel, register group g4 = 4 consecutive output channels 8*g4 + 4*lh .. +3 of the n tile
@@ -244,6 +261,7 @@ __global__ void __launch_bounds__(256, 2)
         const int hw = p.mbi * 128;
         const int img = mrow / hw;
         float* prow = p.chstats + (((size_t)img * p.mbi + (mrow - img * hw) / 128) * 2) * p.N;
+        f32x4 keep_s[TN][4], keep_q[TN][4];          // (TM == 2 only)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -269,10 +287,35 @@ __global__ void __launch_bounds__(256, 2)
                     }
                 }
                 sum8_over_32_lanes(ssum, ssq);            // DPP adds (nd_conv_common.h); the totals sit in lanes 16..31 / 48..63
-                if (l31 == 31 && n + 3 < p.N) {
-                    *reinterpret_cast<f32x4*>(prow + n) = ssum;
-                    *reinterpret_cast<f32x4*>(prow + p.N + n) = ssq;
+                if constexpr (TM == 4) {
+                    if (l31 == 31 && n + 3 < p.N) {
+                        *reinterpret_cast<f32x4*>(prow + n) = ssum;
+                        *reinterpret_cast<f32x4*>(prow + p.N + n) = ssq;
+                    }
+                } else {
+                    // 128-pixel blocks: a wave row is 64 pixels, a statistics row 128 -- the lower wave row hands its sums to the
+                    // upper one through LDS behind the stages (bytes 49152..; the stages of a 128-pixel block end at 49152)
+                    f32x4* xs = reinterpret_cast<f32x4*>(smem + 49152 / 4) + (((wn * TN + ni) * 4 + g4) * 2 + lh) * 2;
+                    if (wm == 1 && l31 == 31) { xs[0] = ssum; xs[1] = ssq; }
+                    keep_s[ni][g4] = ssum;
+                    keep_q[ni][g4] = ssq;
                 }
+            }
+        }
+        if constexpr (TM == 2) {
+            __syncthreads();
+            if (wm == 0 && l31 == 31) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int n = n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh;
+                        if (n + 3 < p.N) {
+                            const f32x4* xs = reinterpret_cast<const f32x4*>(smem + 49152 / 4) + (((wn * TN + ni) * 4 + g4) * 2 + lh) * 2;
+                            *reinterpret_cast<f32x4*>(prow + n) = keep_s[ni][g4] + xs[0];
+                            *reinterpret_cast<f32x4*>(prow + p.N + n) = keep_q[ni][g4] + xs[1];
+                        }
+                    }
             }
         }
         return;
@@ -316,25 +359,22 @@ __global__ void __launch_bounds__(256, 2)
     }
 }
 
-int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s) {
-    const size_t lds = (size_t)64 * 1024;
-    if (a.chstats) {          // (the host admits statistics without a fused GroupNorm only)
-        auto kern = gemm4_kernel<false, true>;
-        static bool attr_set[kMaxDevices] = {};
-        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-    } else if (a.gnA) {
-        auto kern = gemm4_kernel<true>;
-        static bool attr_set[kMaxDevices] = {};
-        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-    } else {
-        auto kern = gemm4_kernel<false>;
-        static bool attr_set[kMaxDevices] = {};
-        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-    }
+template <bool GN, bool STATS, int TM>
+static int launch_gemm4_as(const ConvArgs& a, int grid, hipStream_t s) {
+    auto kern = gemm4_kernel<GN, STATS, TM>;
+    static bool attr_set[kMaxDevices] = {};
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, "nd_conv_nhwc")) return rc;
+    // 256-pixel blocks: two 32 KiB stages; 128-pixel blocks: two 16 KiB stages at 0 and 32 KiB + 1 KiB of statistics hand-over
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), TM == 4 ? (size_t)64 * 1024 : (size_t)50176, s, a);
     return check_launch("nd_conv_nhwc");
+}
+
+// tm: 4 = 256-pixel blocks, 2 = 128-pixel blocks (the caller sized a.mt and the grid for it)
+int launch_gemm4(const ConvArgs& a, int grid, hipStream_t s, int tm) {
+    if (a.chstats)          // (the host admits statistics without a fused GroupNorm only)
+        return tm == 2 ? launch_gemm4_as<false, true, 2>(a, grid, s) : launch_gemm4_as<false, true, 4>(a, grid, s);
+    if (a.gnA) return tm == 2 ? launch_gemm4_as<true, false, 2>(a, grid, s) : launch_gemm4_as<true, false, 4>(a, grid, s);
+    return tm == 2 ? launch_gemm4_as<false, false, 2>(a, grid, s) : launch_gemm4_as<false, false, 4>(a, grid, s);
 }
 
 }  // namespace nd

@@ -454,7 +454,7 @@ class UNetPlan:
         else:
             wp = self._packed(weight, pad_c_to)
             rows = 0
-            if ksize == 1 and var == 14 and want_stats and gn[0] is None and rowbias is None and out.ld == N and flags == 0 and \
+            if ksize == 1 and var in (14, 15) and want_stats and gn[0] is None and rowbias is None and out.ld == N and flags == 0 and \
                     _epilogue_stats_mode() != '0':
                 # gemm4_kernel's epilogue leaves the per-channel partial statistics of its output behind (the attention
                 # block's output projection + residual feeds the next block's in_norm): no pass over `out`

@@ -300,12 +300,12 @@ def test_gemm_1x1_and_silu(M, K, N):
     (2, 16, 16, 64, 0, 96, False, None), (2, 16, 16, 64, 32, 200, True, None), (1, 16, 16, 32, 0, 128, True, None),
     (3, 16, 16, 384, 0, 1152, False, 'plain'), (2, 32, 16, 96, 0, 64, True, 'silu'), (4, 32, 32, 192, 192, 192, True, None),
 ])
-def test_gemm4_two_blocks_per_cu(B, H, W, C0, C1, N, res, gn):
-    """gemm4_kernel (variant 14 of nd_conv_nhwc, flat 1x1 only): pixel rows by buffer_load lds with the row advance in
+@pytest.mark.parametrize('names_v', [14, 15])
+def test_gemm4_two_blocks_per_cu(B, H, W, C0, C1, N, res, gn, names_v):
+    """gemm4_kernel (variants 14 / 15 of nd_conv_nhwc = 256- / 128-pixel blocks, flat 1x1 only): pixel rows by buffer_load lds with the row advance in
     the scalar offset, hand-counted waits, two blocks per CU.  Two-source input, N tails, one- and twelve-chunk K,
     residual, GroupNorm(+SiLU) of the input folded into the fragments -- against a float64 linear layer, twice in a row
     from different cache states (the run-ahead loads' registers must stay allocated: see conv_wino4_kernel's test)."""
-    names_v = 14
     C = C0 + C1
     xa, xb = rnd(B, C0, H, W, seed=1) * 1.5 + 0.2, rnd(B, max(C1, 4), H, W, seed=2)
     x = torch.cat([xa, xb[:, :C1]], 1)
@@ -895,10 +895,12 @@ def test_conv_split_k_fp32(B, C0, C1, N, H, W, ksize, opts):
     assert lib().nd_conv_splitk_workspace_floats(B, H, W, N, 32, ksize, 2) < 0      # one chunk cannot be split
 
 
-@pytest.mark.parametrize('B,C0,C1,N,H,W,res', [(4, 384, 0, 384, 32, 32, True), (2, 64, 64, 100, 16, 16, True), (8, 96, 0, 64, 8, 16, False)])
+@pytest.mark.parametrize('B,C0,C1,N,H,W,res', [(4, 384, 0, 384, 32, 32, True), (2, 64, 64, 100, 16, 16, True), (8, 96, 0, 64, 8, 16, False),
+                                               (48, 384, 0, 384, 32, 32, True)])
 def test_conv1x1_gemm4_epilogue_statistics(B, C0, C1, N, H, W, res):
     """nd_conv1x1_stats_nhwc: the bits of nd_conv_nhwc's variant 14 (gemm4_kernel) plus one fp32 row per (image, 128-pixel
-    run) with the per-channel sum / sum of squares of the values it stored; nd_groupnorm_stats_from_partials folds the rows
+    run) with the per-channel sum / sum of squares of the values it stored (the last case is one the entry point runs on
+    128-pixel blocks -- 1152 blocks for 768 slots instead of 576 for 1024 -- where two wave rows make one statistics row); nd_groupnorm_stats_from_partials folds the rows
     into what the float64 statistics kernel computes on the output."""
     C = C0 + C1
     xa = rnd(B, C0, H, W, seed=1)
@@ -932,7 +934,8 @@ def test_conv1x1_gemm4_epilogue_statistics(B, C0, C1, N, H, W, res):
         a_ = torch.full((B * 32 * 2,), float('nan'), dtype=torch.float64, device=DEV)
         _hip.check(lib().nd_groupnorm_stats_from_partials(ps.data_ptr(), N, rows, None, 0, 0, a_.data_ptr(), B, 32, st()))
         b2 = gn_sums(*gn_stats(out.data_ptr(), N, N, None, 0, 0, None, 0, B, H * W), B).flatten().to(DEV)
-        assert ((a_ - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-5
+        # (fp32 rows: measured <= 5.1e-5 of max(|sum|, 1), the largest on a first moment that cancels in the 48-image case)
+        assert ((a_ - b2).abs() / b2.abs().clamp(min=1.0)).max().item() < 1e-4
     ps2 = torch.full_like(ps, float('nan'))
     _hip.check(lib().nd_conv1x1_stats_nhwc(xad.data_ptr(), C0, C0, p(xbd), C1, C1, wd.data_ptr(), bd.data_ptr(), p(rd), N if res else 0,
                                            out.data_ptr(), N, B, H, W, N, 0, ps2.data_ptr(), st()))
