@@ -104,6 +104,23 @@ int nd_conv1x1_stats_rows(int NI, int H, int W, int N);
 int nd_conv1x1_stats_nhwc(const float* x0, int C0, int ldx0, const float* x1, int C1, int ldx1,
                           const float* w, const float* bias, const float* residual, int ldr, float* out, int ldo,
                           int NI, int H, int W, int N, int flags, float* chstats, nd_stream_t stream);
+/* ---- K5 at the two ends of the UNet (csrc/nd_conv_edge.hip).
+ * First convolution, Conv2d(in_channels <= 4, N, 3, padding=1) on the NHWC4 input (model.py:427-431): K = 4 channels x 9 taps
+ * on v_mfma_f32_16x16x4_f32 with the pixel's four channels as the k index; W % 16 == 0, N % 16 == 0, N <= 256, ldx == 4.
+ * w: nd_repack_conv_first_weight(OIHW [N][C0][3][3]) -> nd_conv_first_weight_floats(N) floats.  chstats | NULL: per-channel
+ * partial statistics of the output, [NI][rows][sum | sum of squares][N] fp32 with rows = nd_conv3x3_first_stats_rows()
+ * (0: shape not supported), every row written by every launch; folded by nd_groupnorm_stats_from_partials. */
+int64_t nd_conv_first_weight_floats(int N);
+int nd_repack_conv_first_weight(const float* w_oihw, float* out, int N, int C0, nd_stream_t stream);
+int nd_conv3x3_first_stats_rows(int NI, int H, int W, int N);
+int nd_conv3x3_first_nhwc(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int NI, int H,
+                          int W, int N, float* chstats, nd_stream_t stream);
+/* Last convolution, Conv2d(C, N <= 7, 3, padding=1) behind GroupNorm + SiLU (model.py:446-449), second half: the caller
+ * runs ONE 1x1 convolution P[px][tap * N + n] = sum_c act(x[px][c]) w[n][c][ky][kx], tap = 3 ky + kx (nd_conv_nhwc with the
+ * norm in its loader and the [9 N (padded)][C] weight), and this entry adds the nine shifted taps:
+ * out[y][x][n] = bias[n] + sum_tap P[y + ky - 1][x + kx - 1][tap * N + n], zero outside the image.  ldp >= 9 N, even. */
+int nd_conv3x3_taps_gather_nhwc(const float* P, int ldp, const float* bias, float* out, int ldo, int NI, int H, int W, int N,
+                                nd_stream_t stream);
 /* The same convolution split over K, for layers whose output has too few tiles to fill the chip and whose contraction is
  * long (7x7 .. 16x16 maps at small batch; the reference runs them as ordinary Conv2d, model.py:166-182): `splits` (2..16)
  * block rows each run a range of whole 32-channel chunks of the (concatenated) input and leave raw accumulators in
@@ -369,11 +386,19 @@ int nd_nhwc_to_nchw(const float* src, float* dst, int NI, int C, int HW, int ld,
  */
 int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step, int64_t* t_out, int B, nd_stream_t stream);
 int nd_step_advance(int32_t* step, int delta, nd_stream_t stream);
-int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
+/* out[0 .. row_floats) = table[*step - lo][0 .. row_floats) for a [rows][row_floats] fp32 table: the step body picks this
+ * step's precomputed embedding rows (K1/K2 of every step of a chain evaluated once, before the loop; model.py:197,348-352
+ * depend on t and y only) by the device step word, so the captured graph needs no timestep MLP.  row_floats % 4 == 0,
+ * 16-byte aligned pointers; a step word outside [lo, lo + rows) reads the nearest row (never outside the table). */
+int nd_copy_row_by_step(const float* table, const int32_t* step, int lo, int rows, int64_t row_floats, float* out,
+                        nd_stream_t stream);
+/* x_dup | NULL: second destination of the updated images (classifier-free guidance: the unconditional half of the next
+ * forward's input batch, diffusion.py:281,344 evaluate the model on the same x_t twice); not x, not x_out. */
+int nd_ddim_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, float eta,
                  const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                  uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);
-int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
+int nd_ddpm_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
                  float guidance_w, const float* coef, const int32_t* step, int var_kind,
                  const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                  uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);

@@ -56,6 +56,7 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, int t, uint64_t id
 struct StepArgs {
     const float* x;
     float* x_out;
+    float* x_dup;      // if set, a second copy of x_out (the unconditional half of a classifier-free batch reads it)
     const float* eps;
     const float* eps_u;
     const float* coef;
@@ -135,7 +136,9 @@ __global__ void __launch_bounds__(256) step_elem_kernel(const StepArgs a) {
         const float e = mix_eps(a, a.eps[pe + c], a.eps_u ? a.eps_u[pe + c] : 0.f);
         float nz = 0.f;
         if (need_nz) nz = a.noise ? a.noise[(size_t)t * a.noise_stride + px] : philox_normal(seed, t, a.idx0 + (uint64_t)it);
-        a.x_out[px] = DDIM ? ddim_elem(k, xt, e, nz) : ddpm_elem(a, cf, t, xt, e, learned ? a.eps[pe + a.C + c] : 0.f, nz);
+        const float o = DDIM ? ddim_elem(k, xt, e, nz) : ddpm_elem(a, cf, t, xt, e, learned ? a.eps[pe + a.C + c] : 0.f, nz);
+        a.x_out[px] = o;
+        if (a.x_dup) a.x_dup[px] = o;
     }
 }
 
@@ -182,6 +185,7 @@ __global__ void __launch_bounds__(256) step_pixel_kernel(const StepArgs a) {
             o[c] = DDIM ? ddim_elem(k, xv[c], e, nz[c]) : ddpm_elem(a, cf, t, xv[c], e, lv, nz[c]);
         }
         *reinterpret_cast<f32x4*>(a.x_out + pix * 4) = o;
+        if (a.x_dup) *reinterpret_cast<f32x4*>(a.x_dup + pix * 4) = o;
     }
 }
 
@@ -204,7 +208,17 @@ __global__ void step_advance_kernel(int32_t* step, int delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += delta;
 }
 
-static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, int ldx, const float* eps,
+// row (*step - lo) of a [rows][n4] table -> out; a step word outside [lo, lo + rows) copies the nearest row (the host
+// checks the range of the chain before it starts; the device never reads outside the table)
+__global__ void __launch_bounds__(256) copy_row_by_step_kernel(const f32x4* table, const int32_t* step, int lo, int rows,
+                                                                long n4, f32x4* out) {
+    int r = *step - lo;
+    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    const f32x4* src = table + (size_t)r * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) out[i] = src[i];
+}
+
+static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, float* x_dup, int ldx, const float* eps,
                        const float* eps_u, int ld_eps, float w, const float* coef, const int32_t* step, float eta,
                        int var_kind, const float* noise, int64_t noise_stride, uint64_t seed, const uint64_t* seed_dev, uint64_t first_elem, int B,
                        int HW, int C, nd_stream_t stream) {
@@ -214,11 +228,13 @@ static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, 
     ND_REQUIRE(ld_eps >= need, fn, "model output has too few channels for this variance kind");
     ND_REQUIRE(var_kind >= 0 && var_kind <= 2, fn, "bad var_kind");
     StepArgs a;
-    a.x = x; a.x_out = x_out; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
+    a.x = x; a.x_out = x_out; a.x_dup = x_dup; a.eps = eps; a.eps_u = eps_u; a.coef = coef; a.step = step; a.noise = noise;
     a.noise_stride = noise_stride; a.seed = seed; a.seed_dev = seed_dev; a.idx0 = first_elem; a.ldx = ldx; a.ld_eps = ld_eps; a.HW = HW; a.C = C; a.w = w;
     a.eta = eta; a.var_kind = var_kind; a.total = (long)B * HW * C;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ND_REQUIRE(!x_dup || (x_dup != x && x_dup != x_out), fn, "x_dup must be a third buffer");
     const bool image_form = ldx == 4 && (ld_eps == 4 || ld_eps == 8) && C <= 4 && aligned16(x) && aligned16(x_out) &&
+                            (!x_dup || aligned16(x_dup)) &&
                             aligned16(eps) && (!eps_u || aligned16(eps_u)) &&
                             (!noise || (aligned16(noise) && (noise_stride & 3) == 0));
     if (image_form) {
@@ -249,19 +265,19 @@ static int launch_step(bool ddim, const char* fn, const float* x, float* x_out, 
 
 using namespace nd;
 
-extern "C" int nd_ddim_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
+extern "C" int nd_ddim_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, float eta,
                             const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                             uint64_t first_elem, int B, int HW, int C, nd_stream_t stream) {
-    return launch_step(true, "nd_ddim_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, eta,
+    return launch_step(true, "nd_ddim_step", x, x_out, x_dup, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, eta,
                        ND_VAR_FIXED, noise, noise_step_stride, seed, seed_dev, first_elem, B, HW, C, stream);
 }
 
-extern "C" int nd_ddpm_step(const float* x, float* x_out, int ldx, const float* eps, const float* eps_uncond,
+extern "C" int nd_ddpm_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond,
                             int ld_eps, float guidance_w, const float* coef, const int32_t* step, int var_kind,
                             const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                             uint64_t first_elem, int B, int HW, int C, nd_stream_t stream) {
-    return launch_step(false, "nd_ddpm_step", x, x_out, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, 0.f,
+    return launch_step(false, "nd_ddpm_step", x, x_out, x_dup, ldx, eps, eps_uncond, ld_eps, guidance_w, coef, step, 0.f,
                        var_kind, noise, noise_step_stride, seed, seed_dev, first_elem, B, HW, C, stream);
 }
 
@@ -290,6 +306,19 @@ extern "C" int nd_fill_timestep(const int64_t* timestep_map, const int32_t* step
     ND_REQUIRE(timestep_map && step && t_out && B > 0, fn, "bad arguments");
     hipLaunchKernelGGL(fill_timestep_kernel, dim3((B + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), timestep_map, step, t_out, B);
+    return check_launch(fn);
+}
+
+extern "C" int nd_copy_row_by_step(const float* table, const int32_t* step, int lo, int rows, int64_t row_floats,
+                                   float* out, nd_stream_t stream) {
+    const char* fn = "nd_copy_row_by_step";
+    ND_REQUIRE(table && step && out && rows > 0 && row_floats > 0, fn, "bad arguments");
+    ND_REQUIRE((row_floats & 3) == 0 && aligned16(table) && aligned16(out), fn, "rows must be multiples of 16 bytes, 16-byte aligned");
+    long g = (row_floats / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(copy_row_by_step_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4*>(table), step, lo, rows, (long)(row_floats / 4),
+                       reinterpret_cast<f32x4*>(out));
     return check_launch(fn);
 }
 

@@ -193,6 +193,11 @@ def _winograd_f4():
     return int(os.environ.get('ND_WINOGRAD_F4', '1'))
 
 
+def _edge_convs():
+    """ND_EDGE_CONVS=0: the first / last convolutions go through the general 3x3 kernels (A/B switch)."""
+    return os.environ.get('ND_EDGE_CONVS', '1') != '0'
+
+
 def _fuse_gn_mode():
     """0: never fold GroupNorm into the consumer conv; 1 (default): fold the affine-only norms (attention); 2: also fold
     norm+SiLU.  Measured: a conv with N/BN output-channel blocks re-evaluates SiLU for every block and halo overlap
@@ -348,7 +353,7 @@ class UNetPlan:
         return out
 
     def conv(self, src, weight, bias, N, ksize, out=None, src2=None, rowbias=None, ld_rowbias=0,
-             residual=None, flags=0, label='conv', pad_c_to=None, want_stats=False):
+             residual=None, flags=0, label='conv', pad_c_to=None, want_stats=False, fuse_gn=False):
         """Emit one convolution.  ``src`` (and optional ``src2``, concatenated after it) are Acts; ``weight`` is the
         module's parameter (packed here); output spatial size is src's, doubled when CONV_IN_UP2X is set.  For 3x3
         convolutions on even sizes the Winograd F(2x2,3x3) kernel competes with the direct kernel's tile shapes and
@@ -356,6 +361,13 @@ class UNetPlan:
         if self.bf16:
             return self._conv_bf16(src, weight, bias, N, ksize, out, src2, rowbias, ld_rowbias, residual, flags, label,
                                    pad_c_to, want_stats=want_stats)
+        plain = src2 is None and rowbias is None and residual is None and flags == 0 and _edge_convs()
+        if plain and ksize == 3 and isinstance(src, Act) and src.ld == 4 and src.C <= 4 and src.W % 16 == 0 and \
+                N % 16 == 0 and N <= 256 and (out is None or out.ld % 4 == 0):
+            return self._conv_first(src, weight, bias, N, out, label, want_stats)
+        if plain and ksize == 3 and isinstance(src, Normed) and src.src2 is None and 9 * N <= 64 and \
+                (src.src.H * src.src.W) % 256 == 0 and src.C % 32 == 0 and weight.shape[1] == src.C:
+            return self._conv_last(src, weight, bias, N, out, label)
         gn = [None, None, 0]
         tmp = None
         if isinstance(src, Normed):
@@ -364,7 +376,7 @@ class UNetPlan:
             hw = (nm.src.H << up_) * (nm.src.W << up_)
             # the fused form needs one image per block: every tile shape is <= 256 pixels
             mode = _fuse_gn_mode()
-            if (mode >= 2 or (mode == 1 and not nm.silu)) and hw >= 256 and hw % 256 == 0 and rowbias is None:
+            if (fuse_gn or mode >= 2 or (mode == 1 and not nm.silu)) and hw >= 256 and hw % 256 == 0 and rowbias is None:
                 src, src2 = nm.src, nm.src2
                 coefA = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
                 coefB = torch.empty(nm.src.NI * nm.C, dtype=torch.float32, device=self.device)
@@ -472,6 +484,54 @@ class UNetPlan:
         self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
         if tmp is not None:
             self._release(tmp)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ the two end convs
+    def _conv_first(self, src, weight, bias, N, out, label, want_stats):
+        """Conv2d(in_channels <= 4, N, 3) on the NHWC4 input (model.py:427-431): nd_conv3x3_first_nhwc, which also leaves the
+        per-channel partial statistics of its output for the first residual block's in_norm."""
+        lib = self.lib
+        NI, H, W = src.NI, src.H, src.W
+        if out is None:
+            out = self._new(NI, H, W, N)
+        w = weight.detach().contiguous()
+        C0 = w.shape[1]
+        wq = torch.empty(lib.nd_conv_first_weight_floats(N), dtype=torch.float32, device=self.device)
+        _hip.check(lib.nd_repack_conv_first_weight(w.data_ptr(), wq.data_ptr(), N, C0, self._stream()),
+                   'nd_repack_conv_first_weight')
+        self.keep.append(wq)
+        self.packed_floats += wq.numel()
+        ph = None
+        if want_stats and out.ld == N and _epilogue_stats_mode() != '0' and NI * H * W * N > _gn_fused_max_elems(False):
+            rows = lib.nd_conv3x3_first_stats_rows(NI, H, W, N)
+            if rows > 0:
+                ph = ('chpart', self._cs_floats)
+                out.cs = (ph, rows)
+                self._cs_floats += (NI * rows * 2 * N + 3) // 4 * 4
+        fl = 2 * NI * H * W * N * 9 * src.C
+        self._emit(lib.nd_conv3x3_first_nhwc, [src.ptr, src.ld, wq.data_ptr(), bias, out.ptr, out.ld, NI, H, W, N, ph], label,
+                   flops=fl, variant=('first', 0), ksize=3, shape=(NI, H, W, src.C, N))
+        self.flops += fl
+        self.conv_flops[label] = self.conv_flops.get(label, 0) + fl
+        return out
+
+    def _conv_last(self, nm, weight, bias, N, out, label):
+        """GroupNorm -> SiLU -> Conv2d(C, N <= 7, 3) (model.py:446-449) with the taps in the GEMM's N dimension: one 1x1
+        convolution over the RAW tensor with the norm in its loader (one n block: the fold is evaluated once, the
+        normalised tensor is never written) leaves P[px][tap * N + n]; nd_conv3x3_taps_gather_nhwc adds the nine shifts."""
+        NI, H, W, C = nm.src.NI, nm.src.H, nm.src.W, nm.C
+        if out is None:
+            out = self._new(NI, H, W, N)
+        w = weight.detach()
+        wt = torch.zeros(64, C, dtype=torch.float32, device=self.device)
+        wt[:9 * N] = w.permute(2, 3, 0, 1).reshape(9 * N, C)
+        self.keep.append(wt)
+        before = self.flops
+        P = self.conv(nm, wt, None, 64, 1, label=label + '.taps', fuse_gn=True)
+        fl = 2 * NI * H * W * N * 9 * C
+        self.flops = before + fl          # the model's flops, not the padded GEMM's
+        self._emit(self.lib.nd_conv3x3_taps_gather_nhwc, [P.ptr, P.ld, bias, out.ptr, out.ld, NI, H, W, N], label + '.gather')
+        self._release(P)
         return out
 
     def _stats_ready(self, nm):
@@ -741,8 +801,11 @@ class UNetPlan:
             return heur
         f4_ok = ksize == 3 and _winograd_f4() and single and gn[0] is None and C % 32 == 0 and \
             (pad_c_to is None or pad_c_to % 32 == 0) and self.lib.nd_conv_winograd_f4_stats_rows(0, NI, H, W) > 0
+        # 1x1 whose output feeds a norm that reads per-channel partial rows: gemm4_kernel's epilogue can leave them
+        st1 = ksize == 1 and stats_wanted and not has_rb and flags == 0 and out is not None and \
+            self.lib.nd_conv1x1_stats_rows(NI, H, W, N) > 0
         ck = (self.device.index,) + key + (('sk%d' % _f32_splitk(),) if splitk_ok else ()) + \
-            (('f4%d%s' % (_winograd_f4(), 's' if stats_wanted else ''),) if f4_ok else ())
+            (('f4%d%s' % (_winograd_f4(), 's' if stats_wanted else ''),) if f4_ok else ()) + (('s1',) if st1 else ())
         if ck in _TUNED:
             c = _TUNED[ck]
             return (c[0], (c[1], c[2])) if c[0].endswith('+splitk') else c
@@ -776,7 +839,7 @@ class UNetPlan:
         # a candidate that leaves no per-channel statistics behind costs the norms that read its output one pass over it
         # (nd_groupnorm_channel_partials_nhwc); only conv_wino4_kernel and conv_wf4_kernel (one pass, not split) write them
         pass_ms = 0.0
-        if stats_wanted and f4_ok and out is not None:
+        if stats_wanted and (f4_ok or st1) and out is not None:
             nb = self.lib.nd_groupnorm_stats_blocks(NI, H * W, N, self.dt)
             if nb > 0:
                 rows_t = torch.empty(NI * nb * 2 * N, dtype=torch.float32, device=self.device)
@@ -786,9 +849,19 @@ class UNetPlan:
         self.keep.pop()                               # tuning copy; the chosen kind is packed again by the caller
         self.packed_floats -= wp.numel()
         for v in range(self.lib.nd_conv_num_variants()):
+            if st1 and v in (14, 15):
+                continue                              # timed below WITH their statistics epilogue
             ms = time_it(self.lib.nd_conv_nhwc, head + [wp.data_ptr()] + tail + [ksize, flags, v] + gn)
             if ms is not None and (best_ms is None or ms + pass_ms < best_ms):
                 best, best_ms = ('direct', v), ms + pass_ms
+        if st1:
+            # nd_conv1x1_stats_nhwc picks the 256- or 128-pixel form itself; no pass over the output to add
+            rows1 = self.lib.nd_conv1x1_stats_rows(NI, H, W, N)
+            sbuf1 = torch.empty(NI * rows1 * 2 * N, dtype=torch.float32, device=self.device)
+            ms = time_it(self.lib.nd_conv1x1_stats_nhwc, head + [wp.data_ptr(), tail[0]] + tail[3:] + [flags, sbuf1.data_ptr()])
+            del sbuf1
+            if ms is not None and (best_ms is None or ms < best_ms):
+                best, best_ms = ('direct', 14), ms
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
             for v in range(self.lib.nd_conv_winograd_num_variants()):      # (retired variant numbers refuse the launch)
@@ -927,6 +1000,85 @@ class UNetPlan:
         return Normed(src=src, src2=src2, C=C, silu=silu, norm=norm, scale_ptr=scale_ptr, shift_ptr=shift_ptr,
                       ld_ss=ld_ss, slot=slot, nblk=nblk, pending=pending)
 
+    # ------------------------------------------------------------------------------------------------ K1/K2
+    def _emit_embedding(self, NR, t_ptr, y_ptr, e_ptr):
+        """Emit K1/K2 for NR rows: t[NR] (int64) and y[NR] -> e[NR][e_ld], the embedding projections of every residual
+        block (model.py:346-352 and the ``step_embedding`` Linear of each block, model.py:155-161,197).  Used with NR = NI
+        inside the forward and with NR = steps * NI by ``embed_table``; returns the scratch buffers (kept alive by the
+        caller)."""
+        m, lib = self.model, self.lib
+        f32 = dict(dtype=torch.float32, device=self.device)
+        mc = m.model_channels
+        ed = 4 * mc
+        temb = torch.zeros(NR * mc, **f32)
+        h1 = torch.empty(NR * ed, **f32)
+        emb = torch.empty(NR * ed, **f32)
+        semb = torch.empty(NR * ed, **f32)
+
+        def packed(key, w):
+            if key not in self._embed_packed:
+                self._embed_packed[key] = self._packed(w)
+            return self._embed_packed[key]
+
+        def gemm(src, K, wkey, w, b, out, N, flags, label):
+            args = [src.data_ptr(), K, K, None, 0, 0, packed(wkey, w).data_ptr(), b.detach().data_ptr(),
+                    None, 0, None, 0, out, N, 1, 1, NR, N, 1, flags, -1, None, None, 0]
+            var = lib.nd_conv_select_variant(1, 1, NR, N, 1, flags, 0)
+            self._emit(lib.nd_conv_nhwc, args, label, flops=2 * NR * N * K, variant=('direct', var), ksize=1)
+            self.flops += 2 * NR * N * K
+
+        self._emit(lib.nd_timestep_embed, [t_ptr, self.freqs.data_ptr(), NR, mc, temb.data_ptr(), mc], 'temb')
+        l0, l2 = m.step_embed[0], m.step_embed[2]
+        gemm(temb, mc, 'l0', l0.weight, l0.bias, h1.data_ptr(), ed, _hip.CONV_SILU_OUT, 'step_embed.0')
+        gemm(h1, ed, 'l2', l2.weight, l2.bias, emb.data_ptr(), ed, 0, 'step_embed.2')
+        if m.conditional:
+            tab = m.class_embedding.weight.detach()
+            self._emit(lib.nd_embedding_add_silu, [emb.data_ptr(), tab.data_ptr(), y_ptr, tab.shape[0], NR, ed,
+                                                   semb.data_ptr()], 'class_emb')
+        else:
+            self._emit(lib.nd_embedding_add_silu, [emb.data_ptr(), None, None, 0, NR, ed, semb.data_ptr()], 'emb_silu')
+        if e_ptr is not None:
+            gemm(semb, ed, 'e', self.e_w, self.e_b, e_ptr, self.e_ld, 0, 'step_embedding.all')
+        return [temb, h1, emb, semb]
+
+    def embed_table_bytes(self, rows):
+        return 4 * rows * self.NI * self.e_ld
+
+    def embed_table(self, t_rows):
+        """K1/K2 of a whole chain at once: ``t_rows`` (int64 [S], the model timestep of every step index the chain will
+        visit) and the labels in ``y_in`` -> fp32 table [S][NI * e_ld] whose row r is exactly what the forward's own K1/K2
+        launches would leave in ``e_all`` at t_rows[r] (same kernels on S * NI rows).  The step body then copies one row
+        (nd_copy_row_by_step) and calls run(skip_embed=True).  Launched on the current stream; storage and launch list
+        are cached per S, so a captured graph that reads the table stays valid across calls."""
+        self._require_current_device()
+        assert self.e_all is not None
+        S = int(t_rows.numel())
+        NI = self.NI
+        et = self._etab
+        if et is None or et['S'] != S:
+            dev = self.device
+            et = dict(S=S, t=torch.zeros(S * NI, dtype=torch.int64, device=dev),
+                      y=None if self.y_in is None else torch.zeros(S * NI, dtype=torch.int64, device=dev),
+                      table=torch.empty(S * NI * self.e_ld, dtype=torch.float32, device=dev))
+            saved = (self.ops, self.meta, self.flops)
+            self.ops, self.meta = [], []
+            try:
+                et['bufs'] = self._emit_embedding(S * NI, et['t'].data_ptr(), None if et['y'] is None else et['y'].data_ptr(),
+                                                  et['table'].data_ptr())
+                et['ops'] = self.ops
+            finally:
+                self.ops, self.meta, self.flops = saved
+            self._etab = et
+        et['t'].view(S, NI).copy_(t_rows.to(self.device).view(S, 1).expand(S, NI))
+        if et['y'] is not None:
+            et['y'].view(S, NI).copy_(self.y_in.view(1, NI).expand(S, NI))
+        stream = self._stream()
+        for fn, args, label in et['ops']:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise _hip.NdHipError('{} ({}, embed_table) failed: {}'.format(fn.__name__, label, _hip.last_error()))
+        return et['table']
+
     # ------------------------------------------------------------------------------------------------ build
     def _build(self):
         m = self.model
@@ -941,23 +1093,6 @@ class UNetPlan:
         # ---- K1/K2: timestep embedding MLP, class embedding, and ALL residual blocks' embedding projections at once
         half = mc // 2
         self.freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / half)).to(dev)
-        self.temb = torch.zeros(NI * mc, **f32)
-        self.h1 = torch.empty(NI * ed, **f32)
-        self.emb = torch.empty(NI * ed, **f32)
-        self.semb = torch.empty(NI * ed, **f32)
-        self._emit(lib.nd_timestep_embed, [self.t_in.data_ptr(), self.freqs.data_ptr(), NI, mc, self.temb.data_ptr(),
-                                           mc], 'temb')
-        l0, l2 = m.step_embed[0], m.step_embed[2]
-        self.linear(self.temb.data_ptr(), NI, mc, l0.weight, l0.bias, self.h1.data_ptr(), ed,
-                    flags=_hip.CONV_SILU_OUT, label='step_embed.0')
-        self.linear(self.h1.data_ptr(), NI, ed, l2.weight, l2.bias, self.emb.data_ptr(), ed, label='step_embed.2')
-        if m.conditional:
-            tab = m.class_embedding.weight.detach()
-            self._emit(lib.nd_embedding_add_silu, [self.emb.data_ptr(), tab.data_ptr(), self.y_in.data_ptr(),
-                                                   tab.shape[0], NI, ed, self.semb.data_ptr()], 'class_emb')
-        else:
-            self._emit(lib.nd_embedding_add_silu, [self.emb.data_ptr(), None, None, 0, NI, ed,
-                                                   self.semb.data_ptr()], 'emb_silu')
         res_blocks = m._residual_blocks()
         widths = [rb.step_embedding.weight.shape[0] for rb in res_blocks]
         self.e_ld = sum(widths)
@@ -966,15 +1101,16 @@ class UNetPlan:
         for rb, wd in zip(res_blocks, widths):
             self.e_off[id(rb)] = off
             off += wd
+        self.e_all = None
         if res_blocks:
             self.e_w = torch.cat([rb.step_embedding.weight.detach() for rb in res_blocks], 0).contiguous()
             self.e_b = torch.cat([rb.step_embedding.bias.detach() for rb in res_blocks], 0).contiguous()
             self.e_all = torch.empty(NI * self.e_ld, **f32)
-            args = [self.semb.data_ptr(), ed, ed, None, 0, 0, self._packed(self.e_w).data_ptr(), self.e_b.data_ptr(),
-                    None, 0, None, 0, self.e_all.data_ptr(), self.e_ld, 1, 1, NI, self.e_ld, 1, 0, -1, None, None, 0]
-            var = lib.nd_conv_select_variant(1, 1, NI, self.e_ld, 1, 0, 0)
-            self._emit(lib.nd_conv_nhwc, args, 'step_embedding.all', flops=2 * NI * self.e_ld * ed, variant=('direct', var), ksize=1)
-            self.flops += 2 * NI * self.e_ld * ed
+        self._embed_packed = {}
+        self.embed_bufs = self._emit_embedding(NI, self.t_in.data_ptr(), None if self.y_in is None else self.y_in.data_ptr(),
+                                               None if self.e_all is None else self.e_all.data_ptr())
+        self.n_embed = len(self.ops)          # run(skip_embed=True) starts here: e_all was filled from an embed_table row
+        self._etab = None
 
         # ---- the UNet proper
         x = Act(self.x_in, NI, R, R, self.Cin_p)
@@ -1201,11 +1337,12 @@ class UNetPlan:
             raise _hip.NdHipError('plan was built for {} but cuda:{} is current; wrap the call in '
                                   'torch.cuda.device(...)'.format(self.device, torch.cuda.current_device()))
 
-    def run(self):
-        """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out."""
+    def run(self, skip_embed=False):
+        """Launch the whole forward on the current stream: reads x_in / t_in / y_in, writes out.  ``skip_embed``: K1/K2 are
+        not launched -- the caller has filled ``e_all`` with this step's row of ``embed_table``."""
         self._require_current_device()
         stream = self._stream()
-        for fn, args, label in self.ops:
+        for fn, args, label in (self.ops[self.n_embed:] if skip_embed else self.ops):
             rc = fn(*args, stream)
             if rc != 0:
                 raise _hip.NdHipError('{} ({}) failed: {}'.format(fn.__name__, label, _hip.last_error()))

@@ -82,8 +82,13 @@ SIGNATURES = {
     'nd_nhwc_to_nchw': [_vp, _vp, _i, _i, _i, _i, _vp],
     'nd_fill_timestep': [_vp, _vp, _vp, _i, _vp],
     'nd_step_advance': [_vp, _i, _vp],
-    'nd_ddim_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
-    'nd_ddpm_step': [_vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_repack_conv_first_weight': [_vp, _vp, _i, _i, _vp],
+    'nd_conv3x3_first_stats_rows': [_i, _i, _i, _i],
+    'nd_conv3x3_first_nhwc': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    'nd_conv3x3_taps_gather_nhwc': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_copy_row_by_step': [_vp, _vp, _i, _i, _i64, _vp, _vp],
+    'nd_ddim_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_ddpm_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
     'nd_checksum_segments': [_vp, _vp, _i, _vp, _vp],
     'nd_qsample': [_vp, _vp, _vp, _i64, _f, _f, _vp],
     'nd_to_uint8_hwc': [_vp, _i, _vp, _i, _i, _i, _i, _vp],
@@ -92,6 +97,7 @@ _SPECIAL = {
     'nd_version': ([], _i),
     'nd_conv_num_variants': ([], _i),
     'nd_conv_weight_floats': ([_i, _i, _i], _i64),
+    'nd_conv_first_weight_floats': ([_i], _i64),
     'nd_conv_max_weight_read': ([_i, _i, _i, _i], _i64),
     'nd_conv_bf16_weight_elems': ([_i, _i, _i], _i64),
     'nd_conv_bf16_max_weight_read': ([_i, _i, _i, _i, _i], _i64),

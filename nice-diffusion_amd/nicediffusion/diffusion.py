@@ -15,6 +15,7 @@ Training-only pieces of the reference (``loss``, VLB, classifier guidance throug
 """
 import enum
 import math
+import os
 
 import numpy as np
 import torch
@@ -299,11 +300,23 @@ class Diffusion:
         x_state = plan.x_in[:B * HW * plan.Cin_p]
         if cfg:
             plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
+        # the unconditional half of a classifier-free batch: the sampler kernel writes the updated images twice
+        xdup = plan.x_in.data_ptr() + 4 * B * HW * plan.Cin_p if cfg else None
         if model.conditional:
             plan.y_in[:B].copy_(y.to(torch.int64))
             if cfg:
                 plan.y_in[B:].zero_()              # null class = label 0 (diffusion.py:281,344)
         st['step'].fill_(first)
+
+        # K1/K2 depend on (t, y) only: evaluated for every step of this chain in one batched pass before the loop
+        # (model.py:346-352,197); the step body copies its row by the device step word.  ND_HOIST_EMBED=0, or a table
+        # over ND_EMBED_TABLE_MAX_GB (default 8), keeps them inside the forward
+        lo = first - steps_to_do + 1
+        etab = None
+        if (plan.e_all is not None and os.environ.get('ND_HOIST_EMBED', '1') != '0' and steps_to_do > 1 and (NI * plan.e_ld) % 4 == 0 and
+                plan.embed_table_bytes(steps_to_do) <= float(os.environ.get('ND_EMBED_TABLE_MAX_GB', '8')) * 2 ** 30):
+            etab = plan.embed_table(st['tmap'][lo:first + 1])
+        row_floats = NI * plan.e_ld
 
         eps_ptr = plan.out.data_ptr()
         eps_u_ptr = plan.out.data_ptr() + 4 * B * HW * plan.Cout_p if cfg else None
@@ -314,18 +327,21 @@ class Diffusion:
 
         def body():
             s = torch.cuda.current_stream().cuda_stream
-            _hip.check(lib.nd_fill_timestep(st['tmap'].data_ptr(), st['step'].data_ptr(), plan.t_in.data_ptr(), NI, s),
-                       'nd_fill_timestep')
-            plan.run()
+            if etab is not None:
+                _hip.check(lib.nd_copy_row_by_step(etab.data_ptr(), st['step'].data_ptr(), lo, steps_to_do, row_floats,
+                                                   plan.e_all.data_ptr(), s), 'nd_copy_row_by_step')
+                plan.run(skip_embed=True)
+            else:
+                _hip.check(lib.nd_fill_timestep(st['tmap'].data_ptr(), st['step'].data_ptr(), plan.t_in.data_ptr(), NI, s),
+                           'nd_fill_timestep')
+                plan.run()
             if self.use_ddim:
-                rc = lib.nd_ddim_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                rc = lib.nd_ddim_step(xp, xp, xdup, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
                                       st['step'].data_ptr(), eta, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             else:
-                rc = lib.nd_ddpm_step(xp, xp, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                rc = lib.nd_ddpm_step(xp, xp, xdup, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
                                       st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             _hip.check(rc, 'sampler step')
-            if cfg:
-                plan.x_in[B * HW * plan.Cin_p:].copy_(x_state)
             _hip.check(lib.nd_step_advance(st['step'].data_ptr(), -1, s), 'nd_step_advance')
 
         def snapshot():
@@ -340,7 +356,8 @@ class Diffusion:
             import tqdm
             bar = tqdm.tqdm(total=steps_to_do)
         use_graph = self.use_graph and trace is None and steps_to_do > 1
-        gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, first_elem)
+        gkey = (self.use_ddim, cfg, eta, w, var_kind, noise_ptr, noise_stride, first_elem,
+                None if etab is None else (etab.data_ptr(), lo, steps_to_do))
         done = 0
         if use_graph:
             if st['graph'] is None or st['graph_key'] != gkey:

@@ -593,16 +593,22 @@ def test_sampler_step_kernels(kind):
         _hip.check(lib().nd_nchw_to_nhwc(eps6u.to(DEV).data_ptr(), eud.data_ptr(), B, 2 * C, R * R, 8, st()))
         step = torch.tensor([t], dtype=torch.int32, device=DEV)
         out = torch.zeros_like(xd)
+        dup = torch.full_like(xd, 7.0) if cfg else None          # classifier-free: the sampler also writes the second copy
+        dp = dup.data_ptr() if cfg else None
         eu = eud.data_ptr() if cfg else None
         if ddim:
-            rc = lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+            rc = lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), dp, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
                                     step.data_ptr(), eta, nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4, 0, None, 0, B,
                                     R * R, C, st())
         else:
-            rc = lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+            rc = lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), dp, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
                                     step.data_ptr(), d._var_kind(), nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4,
                                     0, None, 0, B, R * R, C, st())
         _hip.check(rc)
+        if cfg:
+            assert torch.equal(dup, out)
+            assert lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8,
+                                      coef.data_ptr(), step.data_ptr(), 0.0, None, 0, 0, None, 0, B, R * R, C, st()) != 0
         got = torch.empty(B, C, R, R, device=DEV)
         _hip.check(lib().nd_nhwc_to_nchw(out.data_ptr(), got.data_ptr(), B, C, R * R, 4, st()))
         assert (got.cpu() - ref).abs().max().item() < 5e-6, (kind, t)
@@ -627,7 +633,7 @@ def test_philox_noise_is_standard_normal():
     outs = []
     for seed in (1, 2):
         out = torch.zeros(n, device=DEV)
-        _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
+        _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
                                       step.data_ptr(), _hip.VAR_FIXED, None, 0, seed, None, 0, B, R * R, C, st()))
         outs.append(out.view(-1, 4)[:, :3].cpu())
     z = outs[0].flatten()
@@ -638,9 +644,24 @@ def test_philox_noise_is_standard_normal():
     # the seed may also come from a device word (what the captured loop uses): same numbers as the by-value seed
     word = torch.tensor([2], dtype=torch.int64, device=DEV)
     out = torch.zeros(n, device=DEV)
-    _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
+    _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
                                   step.data_ptr(), _hip.VAR_FIXED, None, 0, 777, word.data_ptr(), 0, B, R * R, C, st()))
     assert torch.equal(out.view(-1, 4)[:, :3].cpu(), outs[1])
+
+
+def test_copy_row_by_step():
+    """nd_copy_row_by_step: the step body's pick of this step's precomputed K1/K2 rows by the device step word."""
+    rows, n = 5, 4 * 1000 + 8
+    tab = torch.randn(rows, n, device=DEV)
+    out = torch.zeros(n, device=DEV)
+    for lo, word, want in ((0, 3, 3), (2, 2, 0), (2, 6, 4), (2, 0, 0), (2, 9, 4)):          # the last two clamp
+        step = torch.tensor([word], dtype=torch.int32, device=DEV)
+        _hip.check(lib().nd_copy_row_by_step(tab.data_ptr(), step.data_ptr(), lo, rows, n, out.data_ptr(), st()))
+        assert torch.equal(out, tab[want]), (lo, word)
+    step = torch.tensor([0], dtype=torch.int32, device=DEV)
+    assert lib().nd_copy_row_by_step(tab.data_ptr(), step.data_ptr(), 0, rows, n - 1, out.data_ptr(), st()) != 0
+    assert lib().nd_copy_row_by_step(tab.data_ptr(), step.data_ptr(), 0, 0, n, out.data_ptr(), st()) != 0
+    assert lib().nd_copy_row_by_step(None, step.data_ptr(), 0, rows, n, out.data_ptr(), st()) != 0
 
 
 def test_qsample():
@@ -667,10 +688,10 @@ def test_sampler_generic_form_matches_image_form(ddim):
         xd, ed = xd.to(DEV), ed.to(DEV)
         out = torch.zeros_like(xd)
         if ddim:
-            _hip.check(lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+            _hip.check(lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), None, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
                                           step.data_ptr(), 0.6, None, 0, 99, None, 0, B, HW, C, st()))
         else:
-            _hip.check(lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+            _hip.check(lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), None, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
                                           step.data_ptr(), _hip.VAR_LEARNED_INTERP, None, 0, 99, None, 0, B, HW, C, st()))
         outs.append(out[..., :C].cpu())
     assert torch.isfinite(outs[0]).all() and (outs[0] - x).abs().max().item() > 1e-3
@@ -1237,3 +1258,103 @@ def test_repack_conv_weight_winograd_f4():
         want = U[n, c, xi, nu].float().item() if n < N else 0.0
         assert o[cq, nb, xi, j, nu, lane, ct].item() == want, (cq, nb, xi, j, nu, lane, ct)
     assert (o[nc - 1] == 0).all() and (o[:, 1, :, :, :, 2:16, 0] == 0).all()          # read-ahead chunk; channels >= N
+
+
+# ------------------------------------------------------------------------------------------------ the two end convolutions
+FIRST_CASES = [(3, 16, 16, 3, 32), (2, 64, 64, 3, 192), (2, 8, 32, 1, 64), (1, 7, 16, 4, 16), (2, 6, 48, 2, 256)]
+
+
+@pytest.mark.parametrize('B,H,W,C0,N', FIRST_CASES)
+def test_conv3x3_first(B, H, W, C0, N):
+    """nd_conv3x3_first_nhwc (K = 4 channels x 9 taps on the 16x16x4 MFMA) against F.conv2d in float64, with and without the
+    output's per-channel partial statistics; run-to-run identical.  Reference: model.py:427-431."""
+    x = rnd(B, C0, H, W, seed=1)
+    w = rnd(N, C0, 3, 3, seed=2, scale=0.3)
+    b = rnd(N, seed=3)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :C0] = x.permute(0, 2, 3, 1)
+    xd, wd, bd = x4.to(DEV).contiguous(), w.to(DEV).contiguous(), b.to(DEV)
+    wq = torch.empty(lib().nd_conv_first_weight_floats(N), device=DEV)
+    _hip.check(lib().nd_repack_conv_first_weight(wd.data_ptr(), wq.data_ptr(), N, C0, st()))
+    out = torch.full((B * H * W * N,), 9.0, device=DEV)
+    _hip.check(lib().nd_conv3x3_first_nhwc(xd.data_ptr(), 4, wq.data_ptr(), bd.data_ptr(), out.data_ptr(), N, B, H, W, N, None, st()))
+    got = from_nhwc(out, B, H, W, N)
+    err = (got.double() - ref).abs().max().item()
+    assert err < 3e-6 * max(1.0, ref.abs().max().item()), err
+    rows = lib().nd_conv3x3_first_stats_rows(B, H, W, N)
+    assert rows == H // (8 if H % 8 == 0 else (4 if H % 4 == 0 else (2 if H % 2 == 0 else 1)))
+    cs = torch.full((B * rows * 2 * N,), 5.0, device=DEV)
+    out2 = torch.zeros_like(out)
+    _hip.check(lib().nd_conv3x3_first_nhwc(xd.data_ptr(), 4, wq.data_ptr(), bd.data_ptr(), out2.data_ptr(), N, B, H, W, N,
+                                           cs.data_ptr(), st()))
+    assert torch.equal(out2, out)
+    rb = H // rows
+    o = out.view(B, rows, rb * W, N).double()
+    want = torch.stack([o.sum(2), (o * o).sum(2)], 2)          # [B][rows][2][N]
+    gotcs = cs.view(B, rows, 2, N).double()
+    assert (gotcs - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    # the fold the plan runs on these rows: float64 group sums of the whole image
+    G = 16 if N % 32 else 32
+    stats = torch.zeros(B * G * 2, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_from_partials(cs.data_ptr(), N, rows, None, 0, 0, stats.data_ptr(), B, G, st()))
+    og = out.view(B, H * W, G, N // G).double()
+    wantg = torch.stack([og.sum((1, 3)), (og * og).sum((1, 3))], 2)
+    assert (stats.view(B, G, 2) - wantg).abs().max().item() < 2e-5 * max(1.0, wantg.abs().max().item())
+    # no bias
+    _hip.check(lib().nd_conv3x3_first_nhwc(xd.data_ptr(), 4, wq.data_ptr(), None, out2.data_ptr(), N, B, H, W, N, None, st()))
+    assert (from_nhwc(out2, B, H, W, N).double() - (ref - b.double().view(1, N, 1, 1))).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_first_refusals():
+    x = torch.zeros(2 * 16 * 16 * 4, device=DEV)
+    w = torch.zeros(9 * 2 * 64, device=DEV)
+    o = torch.zeros(2 * 16 * 16 * 32, device=DEV)
+    call = lambda ldx, ldo, H, W, N: lib().nd_conv3x3_first_nhwc(x.data_ptr(), ldx, w.data_ptr(), None, o.data_ptr(), ldo, 2, H, W, N, None, st())
+    assert call(4, 32, 16, 16, 32) == 0
+    assert call(3, 32, 16, 16, 32) != 0 and 'NHWC4' in _hip.last_error()
+    assert call(4, 32, 16, 12, 32) != 0          # W % 16
+    assert call(4, 32, 16, 16, 24) != 0          # N % 16
+    assert call(4, 16, 16, 16, 32) != 0          # ldo < N
+    assert lib().nd_conv3x3_first_stats_rows(2, 16, 12, 32) == 0 and lib().nd_conv3x3_first_stats_rows(2, 16, 16, 272) == 0
+    assert lib().nd_repack_conv_first_weight(w.data_ptr(), w.data_ptr(), 32, 5, st()) != 0
+    assert lib().nd_conv_first_weight_floats(192) == 9 * 12 * 64 and lib().nd_conv_first_weight_floats(0) < 0
+
+
+@pytest.mark.parametrize('B,H,W,C,N,ldo', [(2, 16, 16, 32, 6, 8), (1, 64, 64, 192, 6, 8), (3, 8, 32, 64, 3, 4), (2, 16, 16, 32, 1, 4),
+                                           (2, 5, 7, 32, 7, 8)])
+def test_last_conv_as_taps_gemm_plus_gather(B, H, W, C, N, ldo):
+    """The last convolution's two halves (model.py:449): P = a . Wt^T with Wt[tap * N + n][c] = w[n][c][ky][kx] through
+    nd_conv_nhwc (1x1), then nd_conv3x3_taps_gather_nhwc; against F.conv2d in float64."""
+    a = rnd(B, C, H, W, seed=4)
+    w = rnd(N, C, 3, 3, seed=5, scale=0.1)
+    b = rnd(N, seed=6)
+    ref = F.conv2d(a.double(), w.double(), b.double(), padding=1)
+    wt = torch.zeros(64, C)
+    wt[:9 * N] = w.permute(2, 3, 0, 1).reshape(9 * N, C)
+    wp = pack_w(wt)
+    ad = nhwc(a)
+    P = torch.zeros(B * H * W * 64, device=DEV)
+    _hip.check(lib().nd_conv_nhwc(ad.data_ptr(), C, C, None, 0, 0, wp.data_ptr(), None, None, 0, None, 0, P.data_ptr(), 64,
+                                  1, 1, B * H * W, 64, 1, 0, -1, None, None, 0, st()))
+    out = torch.full((B * H * W * ldo,), 3.0, device=DEV)
+    bd = b.to(DEV)
+    _hip.check(lib().nd_conv3x3_taps_gather_nhwc(P.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), ldo, B, H, W, N, st()))
+    got = out.view(B, H, W, ldo)[..., :N].permute(0, 3, 1, 2).cpu()
+    assert (got.double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+    if ldo > N:
+        assert (out.view(-1, ldo)[:, N:] == 3.0).all()          # padding channels are not touched
+    # the gather alone, bit for bit against the same sum order in torch (taps ascending, bias first)
+    Pc = P.view(B, H, W, 64).cpu()
+    acc = b.view(1, 1, 1, N).expand(B, H, W, N).clone()
+    for ky in range(3):
+        for kx in range(3):
+            sh = torch.zeros(B, H, W, N)
+            ys, ye = max(0, 1 - ky), min(H, H + 1 - ky)
+            xs, xe = max(0, 1 - kx), min(W, W + 1 - kx)
+            t = ky * 3 + kx
+            sh[:, ys:ye, xs:xe] = Pc[:, ys + ky - 1:ye + ky - 1, xs + kx - 1:xe + kx - 1, t * N:(t + 1) * N]
+            acc = acc + sh
+    assert torch.equal(out.view(B, H, W, ldo)[..., :N].cpu(), acc)
+    assert lib().nd_conv3x3_taps_gather_nhwc(P.data_ptr(), 64, None, out.data_ptr(), ldo, B, H, W, 8, st()) != 0
+    assert lib().nd_conv3x3_taps_gather_nhwc(P.data_ptr(), 9 * N - 1 if N > 1 else 8, None, out.data_ptr(), ldo, B, H, W, N if N > 1 else 2, st()) != 0

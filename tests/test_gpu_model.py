@@ -423,6 +423,41 @@ def test_one_captured_graph_serves_every_seed():
     assert torch.equal(c1, c2) and torch.equal(c1, c3)
 
 
+@pytest.mark.parametrize('cfg_name,guided', [('adagn_updown', True), ('adagn_updown', False), ('plain_convres_legacy', False)])
+def test_embedding_rows_hoisted_out_of_the_loop(monkeypatch, cfg_name, guided):
+    """K1/K2 of every step evaluated before the loop (plan.embed_table + nd_copy_row_by_step) against the same chain with
+    the timestep MLP inside every forward (ND_HOIST_EMBED=0): the table's rows are the forward's own e_all (same kernels
+    on S * NI rows; a different tile may order the K sum differently, hence 2e-6 rather than bit equality), and the
+    classifier-free batch's second copy of x_t now comes from the sampler kernel."""
+    name = cfg_name
+    m = build(TINY_CFGS[name])
+    S = 6
+    d = Diffusion(m, 1000, S, 'learned_interpolation' if TINY_CFGS[name]['out_channels'] == 2 * TINY_CFGS[name]['in_channels'] else 'large',
+                  'simple', beta_schedule='cosine', guidance_method='classifier_free' if guided and m.conditional else None,
+                  guidance_strength=0.7 if guided and m.conditional else None, use_ddim=True, ddim_eta=0.0, device=DEV)
+    R, C = m.resolution, m.in_channels
+    g = torch.Generator().manual_seed(3)
+    xT = torch.randn(3, C, R, R, generator=g)
+    kw = {'y': torch.tensor([1, 2, 3]).to(DEV)} if m.conditional else None
+    on = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False)
+    plan = m._plan(6 if d.guidance == 'classifier_free' else 3)
+    assert plan._etab is not None and plan._etab['S'] == S
+    # row r of the table = what the forward leaves in e_all at that timestep
+    tab = plan._etab['table'].view(S, -1).clone()
+    for r in (0, S - 1):
+        plan.t_in.fill_(int(d.timestep_map[r]))
+        plan.run()
+        torch.cuda.synchronize()
+        assert (tab[r] - plan.e_all).abs().max().item() <= 2e-6 * max(1.0, plan.e_all.abs().max().item())
+    part = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False, steps_to_do=4, first_index=4)      # lo = 1
+    monkeypatch.setenv('ND_HOIST_EMBED', '0')
+    d._loops = {}
+    off = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False)
+    part_off = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False, steps_to_do=4, first_index=4)
+    assert (on - off).abs().max().item() < 2e-5 and (part - part_off).abs().max().item() < 2e-5
+    assert torch.isfinite(on).all()
+
+
 def test_groupnorm_statistics_routes_agree(monkeypatch):
     """Three ways to the same GroupNorm statistics give the same forward, on a model large enough for the autotuner to pick
     the Winograd kernels: (a) ND_GN_PARTIALS=0 + ND_GN_EPILOGUE_STATS=0: one float64 pass over every norm's (concatenated)

@@ -27,3 +27,7 @@ for r in rows:
     if r['fn'] not in CONV or not r['shape']:
         oth[r['fn']] = oth.get(r['fn'], 0) + r['ms']
 print({k: round(v, 3) for k, v in oth.items()})
+if os.environ.get('ND_LAYER_TABLE_OPS'):
+    # every launch in plan order: index, entry point, label, ms
+    for i, r in enumerate(rows):
+        print('%4d %-40s %-44s %8.4f %s' % (i, r['fn'], r['label'], r['ms'], '' if not r['shape'] else ','.join(map(str, r['shape']))))
