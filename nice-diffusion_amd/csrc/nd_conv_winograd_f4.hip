@@ -143,7 +143,7 @@ __device__ __forceinline__ int split_k_args_wf4(ConvArgs& p, int s) {
     return s * p.kchunks * 16;          // channel shift of the input
 }
 
-template <int GW, bool STATS>
+template <int GW, bool STATS, bool PRE>      // PRE: the launch has a residual -- its rows (and the bias vectors) are requested early
 __global__ void __launch_bounds__(768, 3)
     conv_wf4_kernel(const ConvArgs pin) {
     using Geo = Wf4Geo<GW>;
@@ -491,6 +491,45 @@ __global__ void __launch_bounds__(768, 3)
                  : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5])
                  :
                  : "memory");
+    // ---- the two units this wave finishes below (u = xi, xi + 6: output column b, n tile ct): their bias / per-image bias /
+    //      residual vectors are requested NOW, so that their latency (the residual is an HBM miss) passes under the two
+    //      barriers and the LDS round instead of in front of each unit's stores
+    const int t = lane & 15, kq = lane >> 4;
+    const int tli = t >> (THL2 + TWL2);
+    const int tty = (t >> TWL2) & ((1 << THL2) - 1);
+    const int ttx = t & ((1 << TWL2) - 1);
+    const int img = img0 + tli;
+    // (a separate instantiation: without a residual the unchanged code measured 1-2 % faster than this one with the
+    // requests skipped at run time)
+    constexpr bool early = PRE;
+    f32x4 pre_b[2], pre_rb[2], pre_r[2][4];
+    auto load_res = [&](int uu, int nb, int ox) {
+        if (!p.res) return;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = oy0 + 4 * tty + a;
+            if (oy < p.H) {
+                const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
+                                            : ((size_t)(img * p.H + oy) * p.W + ox);
+                pre_r[uu][a] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nb);
+            }
+        }
+    };
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = xi + 6 * uu;
+        const int b = u & 3, ct = u >> 2;
+        const int nb = n0 + ct * 16 + 4 * kq;
+        const int ox = ox0 + 4 * ttx + b;
+        pre_b[uu] = pre_rb[uu] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pre_r[uu][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (early && active && p.vec_ok && nb + 3 < p.N && img < p.NI && ox < p.W) {
+            if (p.bias) pre_b[uu] = *reinterpret_cast<const f32x4*>(p.bias + nb);
+            if (p.rowbias) pre_rb[uu] = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
+            if (uu == 0) load_res(0, nb, ox);
+        }
+    }
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the halo buffers
     f32x4* ex = reinterpret_cast<f32x4*>(smem_all + vb * (kWf4ExchangeBytes / 4));          // this half's [xi][b][ct][lane]
     // M[xi][nu] -> r[b] = sum_nu At[b][nu] M[xi][nu], At = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
@@ -503,12 +542,21 @@ __global__ void __launch_bounds__(768, 3)
         ex[((xi * 4 + 2) * CT + ct) * 64 + lane] = 4.f * s34 + s12;
         ex[((xi * 4 + 3) * CT + ct) * 64 + lane] = (8.f * d34 + d12) + acc[5][ct];
     }
-    const int t = lane & 15, kq = lane >> 4;
-    const int tli = t >> (THL2 + TWL2);
-    const int tty = (t >> TWL2) & ((1 << THL2) - 1);
-    const int ttx = t & ((1 << TWL2) - 1);
-    const int img = img0 + tli;
-    __syncthreads();
+    {
+        // the accumulators are dead: the second unit's residual rows fit now
+        const int u = xi + 6;
+        const int b = u & 3, ct = u >> 2;
+        const int nb = n0 + ct * 16 + 4 * kq;
+        const int ox = ox0 + 4 * ttx + b;
+        if (PRE && active && p.vec_ok && nb + 3 < p.N && img < p.NI && ox < p.W) load_res(1, nb, ox);
+    }
+    if constexpr (PRE) {
+        // (not __syncthreads(): its fence would wait for the prefetched vectors as well)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
     // wave w finishes units u = w and w + 6 of the 12 (output column b, n tile ct): Y[a][b] = sum_xi At[a][xi] r_xi[b]
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
@@ -528,10 +576,13 @@ __global__ void __launch_bounds__(768, 3)
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
         if (active && nb < p.N && img < p.NI && ox < p.W) {
             const bool vec = p.vec_ok && (nb + 3 < p.N);
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, rbv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv = pre_b[uu], rbv = pre_rb[uu];
+            if (vec && !early) {
+                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                if (p.rowbias) rbv = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
+            }
             if (p.bias) {
-                if (vec) bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
-                else {
+                if (!vec) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (nb + c < p.N) bv[c] = p.bias[nb + c];
@@ -539,8 +590,7 @@ __global__ void __launch_bounds__(768, 3)
             }
             if (p.rowbias) {
                 const float* rbp = p.rowbias + (size_t)img * p.ld_rowbias + nb;
-                if (vec) rbv = *reinterpret_cast<const f32x4*>(rbp);
-                else {
+                if (!vec) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (nb + c < p.N) rbv[c] = rbp[c];
@@ -562,7 +612,7 @@ __global__ void __launch_bounds__(768, 3)
                         // the association of the F(2x2) kernels' vector path: ((y + bias) + rowbias) + residual
                         if (p.bias) o += bv;
                         if (p.rowbias) o += rbv;
-                        if (rp) o += *reinterpret_cast<const f32x4*>(rp);
+                        if (rp) o += pre_r[uu][a];
                         if (p.silu_out) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] = fast_silu(o[c]);
@@ -679,16 +729,15 @@ template <int GW>
 static int launch_wf4(const ConvArgs& a, int grid, hipStream_t s) {
     const char* fn = "nd_conv3x3_winograd_f4_nhwc";
     const size_t lds = 2 * kWf4ExchangeBytes;          // two half blocks
-    if (a.chstats) {
-        static bool attr_set[kMaxDevices] = {};
-        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wf4_kernel<GW, true>), attr_set, fn)) return rc;
-        hipLaunchKernelGGL((conv_wf4_kernel<GW, true>), dim3(grid), dim3(768), lds, s, a);
-    } else {
-        static bool attr_set[kMaxDevices] = {};
-        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(conv_wf4_kernel<GW, false>), attr_set, fn)) return rc;
-        hipLaunchKernelGGL((conv_wf4_kernel<GW, false>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(768), lds, s, a);
-    }
-    return check_launch(fn);
+    const dim3 g(grid, a.ksplit > 1 ? a.ksplit : 1);
+    auto go = [&](auto kern, bool (&attr_set)[kMaxDevices]) -> int {
+        if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), attr_set, fn)) return rc;
+        hipLaunchKernelGGL(kern, g, dim3(768), lds, s, a);
+        return check_launch(fn);
+    };
+    static bool set_sr[kMaxDevices] = {}, set_s[kMaxDevices] = {}, set_r[kMaxDevices] = {}, set_0[kMaxDevices] = {};
+    if (a.chstats) return a.res ? go(conv_wf4_kernel<GW, true, true>, set_sr) : go(conv_wf4_kernel<GW, true, false>, set_s);
+    return a.res ? go(conv_wf4_kernel<GW, false, true>, set_r) : go(conv_wf4_kernel<GW, false, false>, set_0);
 }
 
 // block geometry for a map: 5 = 16x16-pixel regions of one image, 3 = four 8x8 images, 0 = this kernel does not take it

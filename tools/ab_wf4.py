@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of library BUILDS on conv_wf4_kernel (Winograd F(4x4,3x3)):
-    python tools/ab_wf4.py libA.so,libB.so "NI H W C N;..." [rounds] [stats]
+    python tools/ab_wf4.py libA.so,libB.so "NI H W C N;..." [rounds] [stats,res]
 (libs from tools/build_one_variant.sh NAME nd_conv_winograd_f4.hip -D...; timing-only ablations give wrong results)"""
 import ctypes, sys, os, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,9 @@ from nicediffusion import _hip
 libs = sys.argv[1].split(',')
 shapes = [tuple(int(v) for v in s.split()) for s in sys.argv[2].split(';') if s.strip()]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-want_stats = len(sys.argv) > 4 and sys.argv[4] == 'stats'
+opts = sys.argv[4].split(',') if len(sys.argv) > 4 else []
+want_stats = 'stats' in opts
+want_res = 'res' in opts          # residual + per-image bias: the out_conv of a residual block
 L = []
 for path in libs:
     l = ctypes.CDLL(os.path.abspath(path))
@@ -28,6 +30,8 @@ for (NI, H, W, C, N) in shapes:
     torch.manual_seed(0)
     x = torch.randn(NI * H * W * C, device='cuda'); w0 = torch.randn(N, C, 3, 3, device='cuda') * 0.02
     b = torch.randn(N, device='cuda'); out = torch.empty(NI * H * W * N, device='cuda')
+    resid = torch.randn(NI * H * W * N, device='cuda') if want_res else None
+    outs = []
     ws = []
     for l in L:
         w = torch.empty(l.nd_conv_winograd_f4_weight_floats(0, N, C), device='cuda')
@@ -39,10 +43,13 @@ for (NI, H, W, C, N) in shapes:
     res = [[] for _ in L]
     def run(i, n):
         for _ in range(n):
-            assert L[i].nd_conv3x3_winograd_f4_nhwc(x.data_ptr(), C, C, ws[i].data_ptr(), b.data_ptr(), None, 0, None, 0, out.data_ptr(), N,
+            assert L[i].nd_conv3x3_winograd_f4_nhwc(x.data_ptr(), C, C, ws[i].data_ptr(), b.data_ptr(), None, 0, None if resid is None else resid.data_ptr(), N, out.data_ptr(), N,
                                                     NI, H, W, N, 0, 0, None if stats is None else stats.data_ptr(), 1, None, st) == 0
-    for i in range(len(L)): run(i, 2)
-    torch.cuda.synchronize()
+    for i in range(len(L)):
+        run(i, 2)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert all(torch.equal(o, outs[0]) for o in outs), 'builds disagree'
     for r in range(rounds):
         for i in range(len(L)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

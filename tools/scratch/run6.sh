@@ -1,0 +1,6 @@
+set -e
+mkdir -p gpurun_out
+S="64 64 64 192 192;64 64 64 384 192;64 32 32 384 384;64 32 32 768 384;64 16 16 576 576;64 8 8 768 768"
+python tools/ab_wf4.py gpurun_variants/libnd_f4NEW.so,gpurun_variants/libnd_f4PREV.so "$S" 5 stats,res > gpurun_out/wf4_abl_17.log 2>&1
+python tools/ab_wf4.py gpurun_variants/libnd_f4NEW.so,gpurun_variants/libnd_f4PREV.so "$S" 5 stats >> gpurun_out/wf4_abl_17.log 2>&1
+cat gpurun_out/wf4_abl_17.log
