@@ -149,26 +149,59 @@ __global__ void __launch_bounds__(256, 2)
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]));
     };
 
-    f32x16 acc[TM][TN];
+    // ---- the residual seeds the accumulators.  Added in the epilogue it was 64 (128) exposed 16-byte loads per lane, 32 bytes of
+    //      every line per instruction, with every block of the launch in the same phase: 34-43 us on 32x32 384 -> 384
+    //      (tools/time_conv1x1.py).  Requested here, OLDEST of the prologue's VMEM operations, its latency passes under the
+    //      first two chunks' DMAs and the wait below covers it.  out = ((res + sum) + bias): the association differs from
+    //      the other kernels' ((sum + bias) + res) in the last bit.
+    const bool rinit = p.res != nullptr && (p.ldr & 3) == 0 && (p.ldo & 3) == 0 && (p.N & 3) == 0;
+    f32x4 seed[TM][TN][4];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) seed[mi][ni][g4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rinit) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const float* rrow = p.res + (size_t)(m0 + (wm * TM + mi) * 32 + l31) * p.ldr + n0 + wn * TN * 32 + 4 * lh;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float* ptr = rrow + ni * 32 + 8 * g4;
+                    if (n0 + (wn * TN + ni) * 32 + 8 * g4 + 4 * lh + 3 < p.N)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(seed[mi][ni][g4]) : "v"(ptr));
+                }
+        }
+    }
 
     f32x4 afr[2][TM], bfr[2][TN], cfr[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) cfr[i][0] = cfr[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue.  VMEM order: chunk 0's rows, the operands of k-step 0, chunk 1's rows (the order the loop leaves behind)
+    // ---- prologue.  VMEM order: (the residual,) chunk 0's rows, the operands of k-step 0, chunk 1's rows (the order the loop
+    //      leaves behind)
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) dma(k, 0, 0);
     ldC(cfr[0], 0, 0);
     ldB(bfr[0], 0, 0);
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) dma(k, 1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS + NDMA) : "memory");          // chunk 0 has landed: LPS + NDMA younger operations
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS + NDMA) : "memory");          // chunk 0 (and the residual) has landed: LPS + NDMA younger operations
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)          // (ties the seed registers to the wait: not read before it)
+            asm volatile("" : "+v"(seed[mi][ni][0]), "+v"(seed[mi][ni][1]), "+v"(seed[mi][ni][2]), "+v"(seed[mi][ni][3]));
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = seed[mi][ni][e >> 2][e & 3];
     __builtin_amdgcn_s_barrier();
     rdA(afr[0], 0);
     if constexpr (GN) {
@@ -276,7 +309,7 @@ __global__ void __launch_bounds__(256, 2)
                         const size_t opix = (size_t)(mrow + mi * 32 + l31);
                         f32x4 v = {acc[mi][ni][4 * g4 + 0], acc[mi][ni][4 * g4 + 1], acc[mi][ni][4 * g4 + 2], acc[mi][ni][4 * g4 + 3]};
                         if (p.bias) v += bv;
-                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + opix * p.ldr + n);
+                        if (p.res && !rinit) v += *reinterpret_cast<const f32x4*>(p.res + opix * p.ldr + n);
                         if (p.silu_out) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fast_silu(v[e]);
@@ -325,7 +358,7 @@ __global__ void __launch_bounds__(256, 2)
         const int m = m0 + (wm * TM + mi) * 32 + l31;
         if (m < M) {
             const size_t opix = (size_t)m;
-            const float* rr = p.res ? p.res + opix * p.ldr : nullptr;
+            const float* rr = (p.res && !rinit) ? p.res + opix * p.ldr : nullptr;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch table of one eager UNet forward (HIP events): shape, tile variant, ms, TFLOP/s.  GPU box only."""
+"""Per-launch table of one eager UNet forward (HIP events): shape, tile variant, ms, TFLOP/s.  GPU box only.
+    python tools/layer_table.py [forward batch] [workload]      (ND_LAYER_TABLE_OPS=1: every launch in plan order)"""
 import sys, os, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nice-diffusion_amd')); sys.path.insert(0, ROOT)
@@ -7,9 +8,10 @@ import torch
 import bench
 CONV = bench.CONV_FNS
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+WL = sys.argv[2] if len(sys.argv) > 2 else 'config2'          # forward batch B (2x the image batch under guidance)
 from nicediffusion import _engine
-_engine.preload_tune_cache(os.path.join(ROOT, 'profiles', 'tune_cache_config2.json'), override=True)
-margs, model, diff = bench.build(torch.device('cuda'))
+_engine.preload_tune_cache(os.path.join(ROOT, 'profiles', 'tune_cache_%s.json' % WL), override=True)
+margs, model, diff = bench.build(torch.device('cuda'), bench.WORKLOADS[WL])
 plan, rows = bench.kernel_breakdown(model, B, reps=3)
 tot = sum(r['ms'] for r in rows)
 print('forward %.2f ms, %.1f TFLOP/s' % (tot, plan.flops / tot / 1e9))
