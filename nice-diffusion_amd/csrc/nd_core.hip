@@ -55,7 +55,7 @@ extern "C" int nd_checksum_segments(const void* const* ptrs, const int64_t* nbyt
     return nd::check_launch(fn);
 }
 
-extern "C" int nd_version(void) { return 120; }
+extern "C" int nd_version(void) { return 121; }
 
 extern "C" const char* nd_last_error(void) { return nd::g_err; }
 

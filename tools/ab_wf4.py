@@ -12,7 +12,8 @@ shapes = [tuple(int(v) for v in s.split()) for s in sys.argv[2].split(';') if s.
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 opts = sys.argv[4].split(',') if len(sys.argv) > 4 else []
 want_stats = 'stats' in opts
-want_res = 'res' in opts          # residual + per-image bias: the out_conv of a residual block
+want_res = 'res' in opts
+SPLITS = int(os.environ.get('ND_AB_SPLITS', '1'))          # split over K (workspace + reduce pass, as the plan runs the small maps)          # residual + per-image bias: the out_conv of a residual block
 L = []
 for path in libs:
     l = ctypes.CDLL(os.path.abspath(path))
@@ -20,6 +21,7 @@ for path in libs:
         if hasattr(l, name):
             getattr(l, name).argtypes = at; getattr(l, name).restype = ctypes.c_int
     l.nd_conv_winograd_f4_weight_floats.argtypes = [ctypes.c_int] * 3; l.nd_conv_winograd_f4_weight_floats.restype = ctypes.c_int64
+    l.nd_conv_splitk_workspace_floats.argtypes = [ctypes.c_int] * 7; l.nd_conv_splitk_workspace_floats.restype = ctypes.c_int64
     L.append(l)
 st = torch.cuda.current_stream().cuda_stream
 a = torch.randn(4096, 4096, device='cuda')
@@ -39,12 +41,16 @@ for (NI, H, W, C, N) in shapes:
         ws.append(w)
     rows = L[0].nd_conv_winograd_f4_stats_rows(0, NI, H, W)
     stats = torch.empty(NI * rows * 2 * N, device='cuda') if want_stats else None
+    wsp = torch.empty(max(4, L[0].nd_conv_splitk_workspace_floats(NI, H, W, N, C, 3, SPLITS)), device='cuda') if SPLITS > 1 else None
+    if SPLITS > 1:
+        rows = L[0].nd_conv_winograd_f4_splitk_stats_rows(0, NI, H, W)
+        stats = torch.empty(max(4, NI * rows * 2 * N), device='cuda') if want_stats and rows > 0 else None
     fl = 2.0 * NI * H * W * N * 9 * C / 4
     res = [[] for _ in L]
     def run(i, n):
         for _ in range(n):
             assert L[i].nd_conv3x3_winograd_f4_nhwc(x.data_ptr(), C, C, ws[i].data_ptr(), b.data_ptr(), None, 0, None if resid is None else resid.data_ptr(), N, out.data_ptr(), N,
-                                                    NI, H, W, N, 0, 0, None if stats is None else stats.data_ptr(), 1, None, st) == 0
+                                                    NI, H, W, N, 0, 0, None if stats is None else stats.data_ptr(), SPLITS, None if wsp is None else wsp.data_ptr(), st) == 0
     for i in range(len(L)):
         run(i, 2)
         torch.cuda.synchronize()
