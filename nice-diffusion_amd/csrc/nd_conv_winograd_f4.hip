@@ -619,6 +619,9 @@ __global__ void __launch_bounds__(768, 3)
                         }
 #if defined(ND_F4ABL_NOSTORE)
                         if (o[0] == 123.456f) *reinterpret_cast<f32x4*>(op) = o;          // timing only
+#elif defined(ND_F4ABL_COALSTORE)
+                        // timing only (wrong placement): the same bytes per workgroup, every store instruction one contiguous KiB
+                        *reinterpret_cast<f32x4*>(p.out + ((size_t)blockIdx.x * 96 + (wv * 8 + uu * 4 + a)) * 256 + lane * 4) = o;
 #else
                         *reinterpret_cast<f32x4*>(op) = o;
 #endif

@@ -55,7 +55,7 @@ for (NI, H, W, C, N) in shapes:
         run(i, 2)
         torch.cuda.synchronize()
         outs.append(out.clone())
-    assert all(torch.equal(o, outs[0]) for o in outs), 'builds disagree'
+    assert os.environ.get('ND_AB_NOCHECK') or all(torch.equal(o, outs[0]) for o in outs), 'builds disagree (ND_AB_NOCHECK=1 for timing-only ablations)'
     for r in range(rounds):
         for i in range(len(L)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
