@@ -320,6 +320,90 @@ __global__ void __launch_bounds__(GN_NT)
     }
 }
 
+// The same pass with one channel vector per thread for the whole block (no pooling): threads = R pixel rows x CQ channel
+// vectors, so a thread's coefficients live in registers and its addresses advance by a constant -- no division and no LDS
+// read per item (gn_apply_kernel spends both on every 16 bytes it moves: 5.3-5.5 TB/s against the 6.0-6.2 TB/s an
+// elementwise pass reaches on these boxes, tools/hbm_yardstick.py).  Same arithmetic per element, same bits.
+// grid: (pixel chunks, NI), block: R * CQ threads (CQ = C / V <= 256).
+template <typename T>
+__global__ void __launch_bounds__(GN_NT)
+    gn_apply_rows_kernel(GnSrc<T> s, const float* addvec, int ld_add, const double* partials, int nchunks, const float* gamma,
+                         const float* beta, const float* scale, const float* shift, int ld_ss, T* out, int ldo,
+                         int HW, int G, float eps, int silu, int pix_per_block, int R) {
+    constexpr int V = GnVec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float shf[];   // A[C] | B[C] | group sums double [G][2]
+    const int C = s.C0 + s.C1;
+    const int CQ = C / V;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int nthr = R * CQ;
+    const int cpg = C / G;
+    const double inv_n = 1.0 / ((double)cpg * (double)HW);
+    float* cA = shf;
+    float* cB = shf + C;
+    double* gs = reinterpret_cast<double*>(shf + 2 * C);
+    for (int i = tid; i < 2 * G; i += nthr) gs[i] = gn_fold_partials(partials, img, nchunks, G, i);
+    __syncthreads();
+    for (int c = tid; c < C; c += nthr) {
+        const int g = c / cpg;
+        const double su = gs[g * 2 + 0];
+        const double sq = gs[g * 2 + 1];
+        const double mean = su * inv_n;
+        double var = sq * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        double a = rstd * (double)gamma[c];
+        double b = (double)beta[c] - mean * a;
+        if (addvec) b += (double)addvec[(size_t)img * ld_add + c] * a;
+        if (scale) {
+            const double sc = 1.0 + (double)scale[(size_t)img * ld_ss + c];
+            a *= sc;
+            b = b * sc + (double)shift[(size_t)img * ld_ss + c];
+        }
+        cA[c] = (float)a;
+        cB[c] = (float)b;
+    }
+    __syncthreads();
+    const int r = tid / CQ, q = tid - r * CQ;
+    const int c = q * V;
+    float a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        a[e] = cA[c + e];
+        b[e] = cB[c + e];
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    int p1 = p0 + pix_per_block;
+    if (p1 > HW) p1 = HW;
+    const size_t ibase = (size_t)img * HW;
+    const bool first = c < s.C0;
+    const T* src = first ? (s.x0 + ibase * s.ldx0 + c) : (s.x1 + ibase * s.ldx1 + (c - s.C0));
+    const size_t lds_ = first ? (size_t)s.ldx0 : (size_t)s.ldx1;
+    T* dst = out + ibase * ldo + c;
+    typedef typename GnVec<T>::Raw Raw;
+    auto one = [&](int px, const Raw& raw) {
+        float v[V], y[V];
+        GnVec<T>::expand(raw, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e] * a[e] + b[e];
+            if (silu) t = fast_silu(t);
+            y[e] = t;
+        }
+        GnVec<T>::store(dst + (size_t)px * ldo, y);
+    };
+    int px = p0 + r;
+    for (; px + 3 * R < p1; px += 4 * R) {
+        Raw v0 = GnVec<T>::raw(src + (size_t)px * lds_), v1 = GnVec<T>::raw(src + (size_t)(px + R) * lds_);
+        Raw v2 = GnVec<T>::raw(src + (size_t)(px + 2 * R) * lds_), v3 = GnVec<T>::raw(src + (size_t)(px + 3 * R) * lds_);
+        one(px, v0);
+        one(px + R, v1);
+        one(px + 2 * R, v2);
+        one(px + 3 * R, v3);
+    }
+    for (; px < p1; px += R) one(px, GnVec<T>::raw(src + (size_t)px * lds_));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Small tensors (launch-bound plans: the EMNIST preset at batch 4 has 54 norms on tensors of 50-400 KB): statistics AND
 // apply in ONE launch.  One block per (group, image) reads its slab (HW pixels x C/G channels, a few KB, L2-resident)
@@ -644,6 +728,16 @@ static int launch_stats(const char* fn, const void* x0, int C0, int ldx0, const 
     return check_launch(fn);
 }
 
+// ND_GN_APPLY_ROWS=0: the item-strided kernel everywhere (A/B switch)
+static bool apply_rows_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ND_GN_APPLY_ROWS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <typename T>
 static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                         const float* addvec, int ld_add, const double* stats, int nchunks, const float* gamma,
@@ -665,7 +759,11 @@ static int launch_apply(const char* fn, const void* x0, int C0, int ldx0, const 
     if (pool)
         hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
                            nchunks, gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
-    else
+    else if (CQ <= GN_NT && C0 % V == 0 && apply_rows_enabled()) {
+        const int R = GN_NT / CQ;          // pixel rows of threads; R * CQ threads (>= 129)
+        hipLaunchKernelGGL((gn_apply_rows_kernel<T>), dim3(chunks, NI), dim3(R * CQ), lds, st, s, addvec, ld_add, stats,
+                           nchunks, gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H * W, G, eps, silu, ppb, R);
+    } else
         hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(chunks, NI), dim3(GN_NT), lds, st, s, addvec, ld_add, stats,
                            nchunks, gamma, beta, scale, shift, ld_ss, static_cast<T*>(out), ldo, H, W, G, eps, silu, ppb);
     return check_launch(fn);
