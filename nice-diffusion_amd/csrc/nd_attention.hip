@@ -32,6 +32,10 @@ struct AttnArgs {
 template <int HDP, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
     attention_kernel(const AttnArgs p) {
+    // K / V tiles prefetched through registers: measured only as a register count -- 16 more registers put the 8-wave
+    // instantiation at 136 (one block per CU instead of two) or, capped at 128, into scratch -- so it is off; the code path
+    // stays for a head dim of 32, where it would fit
+    constexpr bool PRE = false;
     constexpr int AT_NT = WAVES * 64;
     constexpr int AT_BQ = WAVES * 32;      // queries per block
     constexpr int SPR = HDP / 4;           // 16-byte slots per K row
@@ -66,8 +70,9 @@ __global__ void __launch_bounds__(WAVES * 64)
             const int d = 8 * c + 4 * lh;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (d < p.hd) v = *reinterpret_cast<const f32x4*>(qp + d);
+            // softmax scale (and log2 e) folded into Q once: 16 multiplies per 32-key sub-tile fewer beside the MFMAs
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[4 * c + j] = v[j];
+            for (int j = 0; j < 4; ++j) q[4 * c + j] = v[j] * p.scale_log2e;
         }
     }
 
@@ -79,28 +84,63 @@ __global__ void __launch_bounds__(WAVES * 64)
     float m_run = -1e30f, l_run = 0.f;
 
     const int ntiles = (p.T + AT_KT - 1) / AT_KT;
+    // ---- K / V tiles: a thread's pieces of tile kt + 1 are requested right behind the barrier that publishes tile kt and
+    //      sit in registers while tile kt is consumed (the global latency passes under the tile's MFMAs), then go to LDS
+    constexpr int NPC = PRE ? (AT_KT * SPR + AT_NT - 1) / AT_NT : 1;          // 16-byte pieces of K (and of V) per thread and tile
+    f32x4 kreg[NPC], vreg[NPC];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int it = tid + i * AT_NT;
+            const int row = it / SPR;
+            const int sl = it - row * SPR;
+            const int key = kt * AT_KT + row;
+            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it < AT_KT * SPR && key < p.T && sl * 4 < p.hd) {
+                const float* base = p.qkv + (rowbase + key) * p.ld_qkv + hoff + sl * 4;
+                kreg[i] = *reinterpret_cast<const f32x4*>(base + p.k_off);
+                vreg[i] = *reinterpret_cast<const f32x4*>(base + p.v_off);
+            }
+        }
+    };
+    if constexpr (PRE) fetch(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * AT_KT;
         __syncthreads();   // previous tile fully consumed
-        // ---- stage K and V tiles (zero-filled beyond T / hd)
-#if defined(ND_AABL_NOLOAD)
-        if (kt == 0)
-#endif
-        for (int it = tid; it < AT_KT * SPR; it += AT_NT) {
-            const int row = it / SPR;
-            const int sl = it - row * SPR;
-            const int key = key0 + row;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < p.T && sl * 4 < p.hd) {
-                const float* base = p.qkv + (rowbase + key) * p.ld_qkv + hoff + sl * 4;
-                kv = *reinterpret_cast<const f32x4*>(base + p.k_off);
-                vv = *reinterpret_cast<const f32x4*>(base + p.v_off);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int it = tid + i * AT_NT;
+                if (it < AT_KT * SPR) {
+                    const int row = it / SPR;
+                    const int sl = it - row * SPR;
+                    const int swz = (SPR >= 16) ? (row & 15) : ((row >> 1) & 7);
+                    *reinterpret_cast<f32x4*>(Ks + row * HDP + ((sl ^ swz) << 2)) = kreg[i];
+                    *reinterpret_cast<f32x4*>(Vs + row * HDP + (sl << 2)) = vreg[i];
+                }
             }
-            const int swz = (SPR >= 16) ? (row & 15) : ((row >> 1) & 7);
-            *reinterpret_cast<f32x4*>(Ks + row * HDP + ((sl ^ swz) << 2)) = kv;
-            *reinterpret_cast<f32x4*>(Vs + row * HDP + (sl << 2)) = vv;
+        } else {
+            // ---- stage K and V tiles (zero-filled beyond T / hd)
+            for (int it = tid; it < AT_KT * SPR; it += AT_NT) {
+                const int row = it / SPR;
+                const int sl = it - row * SPR;
+                const int key = key0 + row;
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (key < p.T && sl * 4 < p.hd) {
+                    const float* base = p.qkv + (rowbase + key) * p.ld_qkv + hoff + sl * 4;
+                    kv = *reinterpret_cast<const f32x4*>(base + p.k_off);
+                    vv = *reinterpret_cast<const f32x4*>(base + p.v_off);
+                }
+                const int swz = (SPR >= 16) ? (row & 15) : ((row >> 1) & 7);
+                *reinterpret_cast<f32x4*>(Ks + row * HDP + ((sl ^ swz) << 2)) = kv;
+                *reinterpret_cast<f32x4*>(Vs + row * HDP + (sl << 2)) = vv;
+            }
         }
         __syncthreads();
+        if constexpr (PRE) {
+            if (kt + 1 < ntiles) fetch(kt + 1);
+        }
 
 #pragma unroll 1
         for (int sub = 0; sub < AT_KT / 32; ++sub) {
@@ -122,27 +162,32 @@ __global__ void __launch_bounds__(WAVES * 64)
             float mx = -1e30f;
             if (kbase + 32 <= p.T) {          // whole sub-tile inside the sequence (always, when T % 32 == 0): no masks
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s[e] *= p.scale_log2e;
-                    mx = fmaxf(mx, s[e]);
-                }
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    s[e] = (key < p.T) ? s[e] * p.scale_log2e : -1e30f;
+                    s[e] = (key < p.T) ? s[e] : -1e30f;
                     mx = fmaxf(mx, s[e]);
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float ps = 0.f;
+            // (s - m) and the row sum as packed adds (v_pk_add_f32: two elements per instruction)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 mneg = {-m_new, -m_new};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
-                ps += s[e];
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 d = f32x2{s[e], s[e + 1]} + mneg;
+                d[0] = __builtin_amdgcn_exp2f(d[0]);
+                d[1] = __builtin_amdgcn_exp2f(d[1]);
+                s[e] = d[0];
+                s[e + 1] = d[1];
+                ps2 += d;
             }
+            float ps = ps2[0] + ps2[1];
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
