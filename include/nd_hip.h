@@ -340,6 +340,12 @@ int nd_groupnorm_coeffs_from_partials(const float* p0, int C0, int rows0, const 
                                       const float* gamma, const float* beta, const float* scale, const float* shift,
                                       int ld_ss, float* coefA, float* coefB, int ld_coef, int NI, int HW, int G,
                                       float eps, nd_stream_t stream);
+/* The apply pass on READY per-(image, channel) coefficients (nd_groupnorm_coeffs / nd_groupnorm_coeffs_from_partials in front
+ * of it): out = act(x * coefA[img][c] + coefB[img][c]), the same arithmetic and bits as nd_groupnorm_apply_nhwc without its
+ * per-block fold.  (C0 + C1) / V <= 256 and C0 % V == 0 (V = 4 fp32, 8 bf16 elements per 16 bytes); flags: ND_GN_SILU only. */
+int nd_groupnorm_apply_coeffs_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                   const float* coefA, const float* coefB, int ld_coef, void* out, int ldo, int NI, int HW,
+                                   int flags, int dtype, nd_stream_t stream);
 int nd_groupnorm_apply_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
                             const float* addvec, int ld_add, const double* partials, int nblocks,
                             const float* gamma, const float* beta,

@@ -404,6 +404,86 @@ __global__ void __launch_bounds__(GN_NT)
     for (; px < p1; px += R) one(px, GnVec<T>::raw(src + (size_t)px * lds_));
 }
 
+// The apply pass on READY coefficients (nd_groupnorm_coeffs_from_partials in front of it: fold + coefficients in one small
+// launch): y = act(x * A[img][c] + B[img][c]).  No block prologue at all -- gn_apply_rows_kernel's 2 048 blocks each fold the
+// statistics and form their image's coefficients in float64 before the first byte moves.  Same thread layout, same bits.
+template <typename T>
+__global__ void __launch_bounds__(GN_NT)
+    gn_apply_coeffs_kernel(GnSrc<T> s, const float* coefA, const float* coefB, int ld_coef, T* out, int ldo, int HW, int silu,
+                           int pix_per_block, int R) {
+    constexpr int V = GnVec<T>::N;
+    const int C = s.C0 + s.C1;
+    const int CQ = C / V;
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int r = tid / CQ, q = tid - r * CQ;
+    const int c = q * V;
+    float a[V], b[V];
+    {
+        const float* pa = coefA + (size_t)img * ld_coef + c;
+        const float* pb = coefB + (size_t)img * ld_coef + c;
+#pragma unroll
+        for (int e = 0; e < V; e += 4) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(pa + e), vb = *reinterpret_cast<const f32x4*>(pb + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[e + k] = va[k];
+                b[e + k] = vb[k];
+            }
+        }
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    int p1 = p0 + pix_per_block;
+    if (p1 > HW) p1 = HW;
+    const size_t ibase = (size_t)img * HW;
+    const bool first = c < s.C0;
+    const T* src = first ? (s.x0 + ibase * s.ldx0 + c) : (s.x1 + ibase * s.ldx1 + (c - s.C0));
+    const size_t lds_ = first ? (size_t)s.ldx0 : (size_t)s.ldx1;
+    T* dst = out + ibase * ldo + c;
+    typedef typename GnVec<T>::Raw Raw;
+    auto one = [&](int px, const Raw& raw) {
+        float v[V], y[V];
+        GnVec<T>::expand(raw, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e] * a[e] + b[e];
+            if (silu) t = fast_silu(t);
+            y[e] = t;
+        }
+        GnVec<T>::store(dst + (size_t)px * ldo, y);
+    };
+    int px = p0 + r;
+    for (; px + 3 * R < p1; px += 4 * R) {
+        Raw v0 = GnVec<T>::raw(src + (size_t)px * lds_), v1 = GnVec<T>::raw(src + (size_t)(px + R) * lds_);
+        Raw v2 = GnVec<T>::raw(src + (size_t)(px + 2 * R) * lds_), v3 = GnVec<T>::raw(src + (size_t)(px + 3 * R) * lds_);
+        one(px, v0);
+        one(px + R, v1);
+        one(px + 2 * R, v2);
+        one(px + 3 * R, v3);
+    }
+    for (; px < p1; px += R) one(px, GnVec<T>::raw(src + (size_t)px * lds_));
+}
+
+template <typename T>
+static int launch_apply_coeffs(const char* fn, const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                               const float* coefA, const float* coefB, int ld_coef, void* out, int ldo, int NI, int HW,
+                               int flags, hipStream_t st) {
+    constexpr int V = GnVec<T>::N;
+    const int C = C0 + C1, CQ = C / V;
+    ND_REQUIRE(C % V == 0 && C0 % V == 0 && CQ <= GN_NT, fn, "channels must be whole vectors on both sides of the seam, at most 256 vectors");
+    ND_REQUIRE((ldo & (V - 1)) == 0 && ldo >= C && aligned16(out) && (ld_coef & 3) == 0 && aligned16(coefA) && aligned16(coefB), fn, "alignment");
+    int chunks = (2048 + NI - 1) / NI;
+    int ppb = (HW + chunks - 1) / chunks;
+    const int min_ppb = (GN_NT * 4 + CQ - 1) / CQ;
+    if (ppb < min_ppb) ppb = min_ppb;
+    chunks = (HW + ppb - 1) / ppb;
+    const int R = GN_NT / CQ;
+    GnSrc<T> s{static_cast<const T*>(x0), static_cast<const T*>(C1 > 0 ? x1 : x0), C0, C1, ldx0, C1 > 0 ? ldx1 : ldx0};
+    hipLaunchKernelGGL((gn_apply_coeffs_kernel<T>), dim3(chunks, NI), dim3(R * CQ), 0, st, s, coefA, coefB, ld_coef,
+                       static_cast<T*>(out), ldo, HW, (flags & ND_GN_SILU) ? 1 : 0, ppb, R);
+    return check_launch(fn);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Small tensors (launch-bound plans: the EMNIST preset at batch 4 has 54 norms on tensors of 50-400 KB): statistics AND
 // apply in ONE launch.  One block per (group, image) reads its slab (HW pixels x C/G channels, a few KB, L2-resident)
@@ -902,4 +982,21 @@ extern "C" int nd_groupnorm_fused_nhwc(const void* x0, int C0, int ldx0, const v
     }
 #undef ND_GNF_LAUNCH
     return check_launch(fn);
+}
+
+extern "C" int nd_groupnorm_apply_coeffs_nhwc(const void* x0, int C0, int ldx0, const void* x1, int C1, int ldx1,
+                                              const float* coefA, const float* coefB, int ld_coef, void* out, int ldo, int NI,
+                                              int HW, int flags, int dtype, nd_stream_t stream) {
+    const char* fn = "nd_groupnorm_apply_coeffs_nhwc";
+    ND_REQUIRE(dtype == ND_DT_F32 || dtype == ND_DT_BF16, fn, "dtype must be ND_DT_F32 or ND_DT_BF16");
+    ND_REQUIRE(x0 && coefA && coefB && out && NI > 0 && NI <= 65535 && HW > 0 && C0 > 0 && C1 >= 0, fn, "bad arguments");
+    ND_REQUIRE(ldx0 >= C0 && (C1 == 0 || (x1 && ldx1 >= C1)) && ld_coef >= C0 + C1, fn, "strides");
+    ND_REQUIRE((flags & ~ND_GN_SILU) == 0, fn, "only ND_GN_SILU (no pooling in this form)");
+    const int V = dtype == ND_DT_BF16 ? 8 : 4;
+    ND_REQUIRE((ldx0 & (V - 1)) == 0 && (C1 == 0 || (ldx1 & (V - 1)) == 0) && aligned16(x0) && (C1 == 0 || aligned16(x1)), fn,
+               "input rows must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ND_DT_BF16)
+        return launch_apply_coeffs<__bf16>(fn, x0, C0, ldx0, x1, C1, ldx1, coefA, coefB, ld_coef, out, ldo, NI, HW, flags, st);
+    return launch_apply_coeffs<float>(fn, x0, C0, ldx0, x1, C1, ldx1, coefA, coefB, ld_coef, out, ldo, NI, HW, flags, st);
 }

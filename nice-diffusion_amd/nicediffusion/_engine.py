@@ -193,6 +193,11 @@ def _winograd_f4():
     return int(os.environ.get('ND_WINOGRAD_F4', '1'))
 
 
+def _gn_apply_coeffs():
+    """ND_GN_APPLY_COEFFS=0: the apply pass folds its statistics itself (fold launch + nd_groupnorm_apply_nhwc; A/B switch)."""
+    return os.environ.get('ND_GN_APPLY_COEFFS', '1') != '0'
+
+
 def _edge_convs():
     """ND_EDGE_CONVS=0: the first / last convolutions go through the general 3x3 kernels (A/B switch)."""
     return os.environ.get('ND_EDGE_CONVS', '1') != '0'
@@ -556,6 +561,22 @@ class UNetPlan:
 
     def _materialise(self, nm):
         """Fallback for consumers that cannot fuse the GroupNorm affine: write the normalised tensor."""
+        V = 8 if self.bf16 else 4
+        if nm.pending is not None and _gn_apply_coeffs() and nm.C % V == 0 and nm.src.C % V == 0 and nm.C // V <= 256 and \
+                nm.src.ld % V == 0 and (nm.src2 is None or nm.src2.ld % V == 0):
+            # statistics still in partial rows: ONE small launch folds them and writes the coefficients, and the apply pass
+            # streams from its first instruction (no per-block fold / float64 coefficient prologue); same bits
+            NI, HW = nm.src.NI, nm.src.H * nm.src.W
+            coefA = torch.empty(NI * nm.C, dtype=torch.float32, device=self.device)
+            coefB = torch.empty(NI * nm.C, dtype=torch.float32, device=self.device)
+            self.keep += [coefA, coefB]
+            self._emit_coeffs(nm, coefA, coefB)
+            s2 = (None, 0, 0) if nm.src2 is None else (nm.src2.ptr, nm.src2.C, nm.src2.ld)
+            out = self._new(NI, nm.src.H, nm.src.W, nm.C)
+            self._emit(self.lib.nd_groupnorm_apply_coeffs_nhwc,
+                       [nm.src.ptr, nm.src.C, nm.src.ld, s2[0], s2[1], s2[2], coefA.data_ptr(), coefB.data_ptr(), nm.C, out.ptr, out.ld,
+                        NI, HW, _hip.GN_SILU if nm.silu else 0, self.dt], 'gn.apply')
+            return out
         self._stats_ready(nm)
         s2 = (None, 0, 0) if nm.src2 is None else (nm.src2.ptr, nm.src2.C, nm.src2.ld)
         out = self._new(nm.src.NI, nm.src.H, nm.src.W, nm.C)

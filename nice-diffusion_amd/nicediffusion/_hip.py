@@ -86,6 +86,7 @@ SIGNATURES = {
     'nd_conv3x3_first_stats_rows': [_i, _i, _i, _i],
     'nd_conv3x3_first_nhwc': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     'nd_conv3x3_taps_gather_nhwc': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'nd_groupnorm_apply_coeffs_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_copy_row_by_step': [_vp, _vp, _i, _i, _i64, _vp, _vp],
     'nd_ddim_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
     'nd_ddpm_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],

@@ -1358,3 +1358,56 @@ def test_last_conv_as_taps_gemm_plus_gather(B, H, W, C, N, ldo):
     assert torch.equal(out.view(B, H, W, ldo)[..., :N].cpu(), acc)
     assert lib().nd_conv3x3_taps_gather_nhwc(P.data_ptr(), 64, None, out.data_ptr(), ldo, B, H, W, 8, st()) != 0
     assert lib().nd_conv3x3_taps_gather_nhwc(P.data_ptr(), 9 * N - 1 if N > 1 else 8, None, out.data_ptr(), ldo, B, H, W, N if N > 1 else 2, st()) != 0
+
+
+@pytest.mark.parametrize('B,H,W,C0,C1,silu,ada', [(3, 16, 16, 64, 0, True, True), (2, 32, 32, 192, 0, True, False), (2, 16, 16, 96, 32, False, True),
+                                                  (2, 8, 24, 1024, 0, True, True), (1, 5, 7, 32, 32, True, False)])
+def test_groupnorm_apply_on_ready_coefficients(B, H, W, C0, C1, silu, ada):
+    """nd_groupnorm_coeffs_from_partials + nd_groupnorm_apply_coeffs_nhwc (the plan's route for norms whose statistics arrive
+    as partial rows) = nd_groupnorm_stats_from_partials + nd_groupnorm_apply_nhwc, bit for bit; and both against float64."""
+    C, HW, G = C0 + C1, H * W, 32
+    x0 = rnd(B, HW, C0, seed=1).to(DEV).contiguous()
+    x1 = rnd(B, HW, max(C1, 1), seed=2).to(DEV).contiguous()
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(DEV), (0.1 * rnd(C, seed=4)).to(DEV)
+    ss = (0.2 * rnd(B, 2 * C, seed=5)).to(DEV).contiguous()
+    sc, sh = (ss.data_ptr(), ss.data_ptr() + 4 * C) if ada else (None, None)
+    rows = []
+    for x, Cx in ((x0, C0), (x1, C1)):
+        if Cx == 0:
+            rows.append((None, 0))
+            continue
+        nb = lib().nd_groupnorm_stats_blocks(B, HW, Cx, _hip.DT_F32)
+        r = torch.empty(B * nb * 2 * Cx, device=DEV)
+        _hip.check(lib().nd_groupnorm_channel_partials_nhwc(x.data_ptr(), Cx, Cx, r.data_ptr(), B, HW, _hip.DT_F32, st()))
+        rows.append((r, nb))
+    p1 = None if C1 == 0 else rows[1][0].data_ptr()
+    flags = _hip.GN_SILU if silu else 0
+    # route A: fold, then the apply pass that forms its own coefficients
+    stats = torch.zeros(B * G * 2, dtype=torch.float64, device=DEV)
+    _hip.check(lib().nd_groupnorm_stats_from_partials(rows[0][0].data_ptr(), C0, rows[0][1], p1, C1, rows[1][1], stats.data_ptr(), B, G, st()))
+    outA = torch.zeros(B * HW * C, device=DEV)
+    _hip.check(lib().nd_groupnorm_apply_nhwc(x0.data_ptr(), C0, C0, None if C1 == 0 else x1.data_ptr(), C1, C1, None, 0, stats.data_ptr(), 1,
+                                             gamma.data_ptr(), beta.data_ptr(), sc, sh, 2 * C, outA.data_ptr(), C, B, H, W, G, 1e-5, flags,
+                                             _hip.DT_F32, st()))
+    # route B: fold + coefficients in one launch, then the apply pass on ready coefficients
+    cA, cB = torch.zeros(B * C, device=DEV), torch.zeros(B * C, device=DEV)
+    _hip.check(lib().nd_groupnorm_coeffs_from_partials(rows[0][0].data_ptr(), C0, rows[0][1], p1, C1, rows[1][1], gamma.data_ptr(), beta.data_ptr(),
+                                                       sc, sh, 2 * C, cA.data_ptr(), cB.data_ptr(), C, B, HW, G, 1e-5, st()))
+    outB = torch.full((B * HW * C,), 7.0, device=DEV)
+    _hip.check(lib().nd_groupnorm_apply_coeffs_nhwc(x0.data_ptr(), C0, C0, None if C1 == 0 else x1.data_ptr(), C1, C1, cA.data_ptr(), cB.data_ptr(), C,
+                                                    outB.data_ptr(), C, B, HW, flags, _hip.DT_F32, st()))
+    assert torch.equal(outA, outB)
+    xc = torch.cat([x0, x1[..., :C1]], -1).double().cpu() if C1 else x0.double().cpu()
+    xg = xc.view(B, HW, G, C // G)
+    mean, var = xg.mean((1, 3), keepdim=True), xg.var((1, 3), unbiased=False, keepdim=True)
+    y = ((xg - mean) / torch.sqrt(var + 1e-5)).view(B, HW, C) * gamma.double().cpu() + beta.double().cpu()
+    if ada:
+        y = y * (1 + ss[:, :C].double().cpu().view(B, 1, C)) + ss[:, C:].double().cpu().view(B, 1, C)
+    if silu:
+        y = y * torch.sigmoid(y)
+    assert (outB.view(B, HW, C).double().cpu() - y).abs().max().item() < 2e-5
+    # refusals: pooling flag, a seam inside a 16-byte vector, more than 256 vectors
+    call = lambda c0, c1, fl: lib().nd_groupnorm_apply_coeffs_nhwc(x0.data_ptr(), c0, c0, x1.data_ptr(), c1, max(c1, 4), cA.data_ptr(), cB.data_ptr(), c0 + c1,
+                                                                    outB.data_ptr(), c0 + c1, 1, 4, fl, _hip.DT_F32, st())
+    assert call(C0, 0, _hip.GN_SILU | _hip.GN_POOL2) != 0
+    assert call(6, 2, 0) != 0 and call(1028, 0, 0) != 0
