@@ -5,10 +5,11 @@
 //
 // Shape of the kernel (conv_wf4_kernel).  What limits an F(4x4) block on gfx950 is the register file: 36 positions x 256
 // output pixels x 48 channels of fp32 accumulators are 108 KiB.  So:
-//   * block = 6 waves, wave xi owns ROW xi of the 6x6 transform (6 positions) for 16 tiles (a 16x16-pixel region, or four
-//     8x8 images) x 48 output channels on v_mfma_f32_16x16x4_f32: 6 x 3 accumulators of 4 registers = 72; <= 168 registers
-//     per wave, i.e. THREE waves per SIMD = two blocks per CU, so one block's prologue / epilogue / barrier waits sit under
-//     the other's matrix instructions (the conv_wino4_kernel recipe, nd_conv_winograd_quad.hip);
+//   * workgroup = 12 waves = TWO half blocks of 6 (a 6-wave workgroup lands on the SIMDs as 2 + 2 + 1 + 1: 0.73 of the MFMA
+//     rate, tools/micro/mfma_f32_rate.hip); in a half, wave xi owns ROW xi of the 6x6 transform (6 positions) for 16 tiles (a
+//     16x16-pixel region, or four 8x8 images) x 48 output channels on v_mfma_f32_16x16x4_f32: 6 x 3 accumulators of 4
+//     registers = 72; <= 168 registers per wave, i.e. THREE waves per SIMD = one workgroup per CU.  The halves work on the
+//     same m tile and neighbouring n blocks (256 px x 96 ch per workgroup) and share ONE halo stream;
 //   * the input transform B^T d B is computed per wave for its own row only: the row (y) part is 2 (rows 0, 5) or 3 (rows
 //     1..4) fused multiply-adds per column with wave-uniform coefficients, the column (x) part 12 operations per 6
 //     positions; both work on 8-channel half chunks (ds_read_b64) so that the transform's live values stay at 12 + 12
@@ -23,9 +24,12 @@
 //     hipcc orders every LDS read it can see behind ALL pending LDS-DMA;
 //   * ONE barrier per 16-channel chunk: it publishes chunk c + 1 (issued a chunk earlier) and frees chunk c's buffer for
 //     chunk c + 2;
-//   * epilogue: the row part of A^T M A in registers, the xi part through one LDS round (72 KiB), fused bias / per-image
-//     bias / residual (+2x) / SiLU and -- STATS -- the per-channel partial sums of what was stored (one row per (m block,
-//     output column b), folded by nd_groupnorm_stats_from_partials); split over K as conv_wino4_kernel.
+//   * epilogue: the row part of A^T M A in registers, the xi part through one LDS round (72 KiB per half), fused bias /
+//     per-image bias / residual (+2x) / SiLU and -- STATS -- the per-channel partial sums of what was stored (one row per (m
+//     block, output column b), folded by nd_groupnorm_stats_from_partials); split over K as conv_wino4_kernel.  PRE (a launch
+//     with a residual): its vectors are requested before the epilogue's barriers.
+//   Timing-only ablation builds (-DND_F4ABL_*: NOB NOA NOT NOHALO HALOHIT BHIT L1HIT ACF NOBAR NOEPI NOSTORE COALSTORE
+//   NOWAITVM NOWAITLGKM) give WRONG results by construction; tools/ab_wf4.py times them (profiles/r05_wf4_ablations.txt).
 #include "nd_conv_common.h"
 #include <type_traits>
 
