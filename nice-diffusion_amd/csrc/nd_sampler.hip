@@ -2,6 +2,9 @@
 //   nd_ddim_step  <- Diffusion.ddim_denoising_step     diffusion.py:324-367 (everything after the model call)
 //   nd_ddpm_step  <- Diffusion.denoising_step + get_eps_and_log_var   diffusion.py:248-314
 //   nd_qsample    <- Diffusion.diffusion_step          diffusion.py:232-240
+//   nd_fill_timestep / nd_step_advance / nd_copy_row_by_step: the device step word and what the captured step body reads
+//   through it (the model timestep; this step's row of the chain's precomputed K1/K2 table, model.py:197,346-352)
+// Under classifier-free guidance the step kernels also write the unconditional half's copy of x_{t-1} (x_dup).
 // The reference gathers 4-6 per-step scalars with extract() (diffusion.py:478-496: a host->device copy of a whole
 // float64 table, .float(), gather) per call.  Here the tables live on the device as one fp32 row per step and the
 // step index itself is a device word, so the whole step body can be captured in a hipGraph and replayed.
