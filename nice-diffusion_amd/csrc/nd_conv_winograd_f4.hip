@@ -28,7 +28,7 @@
 //     per-image bias / residual (+2x) / SiLU and -- STATS -- the per-channel partial sums of what was stored (one row per (m
 //     block, output column b), folded by nd_groupnorm_stats_from_partials); split over K as conv_wino4_kernel.  PRE (a launch
 //     with a residual): its vectors are requested before the epilogue's barriers.
-//   Timing-only ablation builds (-DND_F4ABL_*: NOB NOA NOT NOHALO HALOHIT BHIT L1HIT ACF NOBAR NOEPI NOSTORE COALSTORE
+//   Timing-only ablation builds (-DND_F4ABL_*: NOB NOA NOT NOHALO HALOHIT BHIT L1HIT ACF NOBAR NOEPI NOSTORE COALSTORE NOPROWAIT
 //   NOWAITVM NOWAITLGKM) give WRONG results by construction; tools/ab_wf4.py times them (profiles/r05_wf4_ablations.txt).
 #include "nd_conv_common.h"
 #include <type_traits>
@@ -398,7 +398,11 @@ __global__ void __launch_bounds__(768, 3)
 #pragma unroll
         for (int k = 0; k < NDMA; ++k) halo_issue(k, 1, 1);
         wf4_sfor<0, 6>([&](auto nuc) { ldfrag(nuc, wf[decltype(nuc)::value], wwave); });
+#if defined(ND_F4ABL_NOPROWAIT)
+        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");         // timing only: the prologue does not wait for its halo chunks
+#else
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // both chunks have landed; the six fragment loads may be in flight
+#endif
         __builtin_amdgcn_s_barrier();
         wf4_sfor<0, 6>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
