@@ -157,6 +157,13 @@ __global__ void __launch_bounds__(768, 3)
     ConvArgs p = pin;
     int cshift = 0;
     if (!STATS && pin.ksplit > 1) cshift = split_k_args_wf4(p, blockIdx.y);
+#if defined(ND_F4_DIAG)
+    // diagnostic build only (tools/wf4_timeline.py): 10 ns stamps of wave 0 go to the buffer passed as `rowbias`, which is then ignored
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_t3 = 0;
+    unsigned* const dg_buf = reinterpret_cast<unsigned*>(const_cast<float*>(p.rowbias));
+    p.rowbias = nullptr;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
 
@@ -404,6 +411,9 @@ __global__ void __launch_bounds__(768, 3)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // both chunks have landed; the six fragment loads may be in flight
 #endif
         __builtin_amdgcn_s_barrier();
+#if defined(ND_F4_DIAG)
+        dg_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
         wf4_sfor<0, 6>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             issue_col(cc, ND_IC(0));
@@ -479,6 +489,9 @@ __global__ void __launch_bounds__(768, 3)
     if (typeA) run(std::true_type{});
     else run(std::false_type{});
 #undef ND_SB
+#if defined(ND_F4_DIAG)
+    dg_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     __builtin_amdgcn_s_setprio(3);
 #if defined(ND_F4ABL_NOEPI)
@@ -511,6 +524,10 @@ __global__ void __launch_bounds__(768, 3)
     // requests skipped at run time)
     constexpr bool early = PRE;
     f32x4 pre_b[2], pre_rb[2], pre_r[2][4];
+    // (inline ISA: as ordinary loads hipcc moved a loaded register right behind one of them, i.e. put an s_waitcnt vmcnt(0) --
+    // a full memory latency -- into the middle of the requests; tools/wf4_timeline.py showed it as 3 us between the loop's end
+    // and the exchange barrier)
+    auto ld128 = [&](f32x4& d, const float* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr)); };
     auto load_res = [&](int uu, int nb, int ox) {
         if (!p.res) return;
 #pragma unroll
@@ -519,7 +536,7 @@ __global__ void __launch_bounds__(768, 3)
             if (oy < p.H) {
                 const size_t rpx = p.res_up ? ((size_t)(img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1))
                                             : ((size_t)(img * p.H + oy) * p.W + ox);
-                pre_r[uu][a] = *reinterpret_cast<const f32x4*>(p.res + rpx * p.ldr + nb);
+                ld128(pre_r[uu][a], p.res + rpx * p.ldr + nb);
             }
         }
     };
@@ -533,8 +550,8 @@ __global__ void __launch_bounds__(768, 3)
 #pragma unroll
         for (int a = 0; a < 4; ++a) pre_r[uu][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (early && active && p.vec_ok && nb + 3 < p.N && img < p.NI && ox < p.W) {
-            if (p.bias) pre_b[uu] = *reinterpret_cast<const f32x4*>(p.bias + nb);
-            if (p.rowbias) pre_rb[uu] = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)img * p.ld_rowbias + nb);
+            if (p.bias) ld128(pre_b[uu], p.bias + nb);
+            if (p.rowbias) ld128(pre_rb[uu], p.rowbias + (size_t)img * p.ld_rowbias + nb);
             if (uu == 0) load_res(0, nb, ox);
         }
     }
@@ -562,9 +579,16 @@ __global__ void __launch_bounds__(768, 3)
         // (not __syncthreads(): its fence would wait for the prefetched vectors as well)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // the requested vectors: in flight since before the column transform / the LDS round; tied to the wait
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(pre_b[0]), "+v"(pre_b[1]), "+v"(pre_rb[0]), "+v"(pre_rb[1]), "+v"(pre_r[0][0]), "+v"(pre_r[0][1]), "+v"(pre_r[0][2]),
+                       "+v"(pre_r[0][3]), "+v"(pre_r[1][0]), "+v"(pre_r[1][1]), "+v"(pre_r[1][2]), "+v"(pre_r[1][3]));
     } else {
         __syncthreads();
     }
+#if defined(ND_F4_DIAG)
+    dg_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
     // wave w finishes units u = w and w + 6 of the 12 (output column b, n tile ct): Y[a][b] = sum_xi At[a][xi] r_xi[b]
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
@@ -695,6 +719,20 @@ __global__ void __launch_bounds__(768, 3)
             }
         }
     }
+#if defined(ND_F4_DIAG)
+    if (wv == 0 && lane == 0 && dg_buf) {
+        const unsigned long long dg_t4 = __builtin_amdgcn_s_memrealtime();
+        unsigned* d = dg_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        d[0] = (unsigned)dg_t0;
+        d[1] = (unsigned)(dg_t1 - dg_t0);
+        d[2] = (unsigned)(dg_t2 - dg_t0);
+        d[3] = (unsigned)(dg_t3 - dg_t0);
+        d[4] = (unsigned)(dg_t4 - dg_t0);
+        d[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));           // HW_ID
+        d[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));          // XCC_ID
+        d[7] = (unsigned)(dg_t0 >> 32);
+    }
+#endif
 }
 #undef ND_IC
 
