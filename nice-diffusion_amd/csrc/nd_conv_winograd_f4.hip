@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(768, 3)
 #if defined(ND_F4_DIAG)
     // diagnostic build only (tools/wf4_timeline.py): 10 ns stamps of wave 0 go to the buffer passed as `rowbias`, which is then ignored
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_t3 = 0;
+    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_t3 = 0, dg_ta = 0, dg_tb = 0;
     unsigned* const dg_buf = reinterpret_cast<unsigned*>(const_cast<float*>(p.rowbias));
     p.rowbias = nullptr;
 #endif
@@ -400,11 +400,17 @@ __global__ void __launch_bounds__(768, 3)
         };
 
         // ---- prologue: chunks 0 and 1, the fragments of k4-step 0, then the transform of chunk 0's first half
+#if defined(ND_F4_DIAG)
+        dg_ta = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int k = 0; k < NDMA; ++k) halo_issue(k, 0, 0);
 #pragma unroll
         for (int k = 0; k < NDMA; ++k) halo_issue(k, 1, 1);
         wf4_sfor<0, 6>([&](auto nuc) { ldfrag(nuc, wf[decltype(nuc)::value], wwave); });
+#if defined(ND_F4_DIAG)
+        dg_tb = __builtin_amdgcn_s_memrealtime();
+#endif
 #if defined(ND_F4ABL_NOPROWAIT)
         asm volatile("s_waitcnt vmcnt(63)" ::: "memory");         // timing only: the prologue does not wait for its halo chunks
 #else
@@ -724,12 +730,12 @@ __global__ void __launch_bounds__(768, 3)
         const unsigned long long dg_t4 = __builtin_amdgcn_s_memrealtime();
         unsigned* d = dg_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         d[0] = (unsigned)dg_t0;
-        d[1] = (unsigned)(dg_t1 - dg_t0);
+        d[1] = (unsigned)(dg_t1 - dg_t0) | ((unsigned)(dg_ta - dg_t0) << 16);          // (spans < 655 us: 16 bits each)
         d[2] = (unsigned)(dg_t2 - dg_t0);
+        d[6] = (__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xffffu) | ((unsigned)(dg_tb - dg_t0) << 16);          // XCC_ID | issue done
         d[3] = (unsigned)(dg_t3 - dg_t0);
         d[4] = (unsigned)(dg_t4 - dg_t0);
         d[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));           // HW_ID
-        d[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));          // XCC_ID
         d[7] = (unsigned)(dg_t0 >> 32);
     }
 #endif

@@ -40,9 +40,13 @@ print('workgroups stamped', len(d))
 t0s = d[:, 0].astype(np.int64) + (d[:, 7].astype(np.int64) << 32)
 base = t0s.min()
 start = (t0s - base) / 100.0           # us (100 MHz)
+ta = (d[:, 1] >> 16) / 100.0          # entry -> first DMA about to be issued (arguments, descriptors, addresses)
+tb = (d[:, 6] >> 16) / 100.0          # ... -> both chunks and the first fragments requested
+d[:, 1] &= 0xffff
 t1, t2, t3, t4 = (d[:, k] / 100.0 for k in (1, 2, 3, 4))
 print('kernel span %.1f us' % (start + t4).max())
 med = np.median
+print('prologue in parts (medians): setup %.2f us | issue of 2 chunks + 6 fragments %.2f us | wait + barrier %.2f us' % (med(ta), med(tb - ta), med(t1 - tb)))
 print('medians: entry -> first barrier (prologue) %.2f us | main loop %.2f us | loop end -> exchange barrier %.2f us | units (reads, transform, '
       'store issue) %.2f us | workgroup life (wave 0) %.2f us' % (med(t1), med(t2 - t1), med(t3 - t2), med(t4 - t3), med(t4)))
 # by CU: (xcc, se, sh, cu) from HW_ID bits: cu_id [11:8], sh_id [12], se_id [15:13]
