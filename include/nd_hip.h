@@ -52,6 +52,14 @@ typedef void* nd_stream_t; /* hipStream_t */
 #define ND_COEF_COLS 8 /* per-step fp32 coefficient row: see nd_ddim_step / nd_ddpm_step */
 
 int nd_version(void);
+/* 16 hex digits of the SHA-256 over the library's sources (every .hip / .h / .inc file under csrc/ and this header, in name
+ * order; the Makefile computes it and every change of one character of any of them changes it).  Measured artefacts --
+ * tune caches, PMC tables, bench lines -- are stamped with it, so "taken on another build" is detected, not remembered. */
+const char* nd_build_id(void);
+/* "" for the product build; otherwise the space-separated NAME=value list of the timing-only / diagnostic macros
+ * (ND_F4ABL_*, ND_HABL_*, ND_WABL_*, ND_*_DIAG, ...; csrc/nd_variant_flags.inc) some translation unit was compiled
+ * with.  Such a library computes wrong results by construction; the Python host refuses it unless ND_ALLOW_ABLATION=1. */
+const char* nd_build_flags(void);
 const char* nd_last_error(void);
 /* gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-"); "" on error. */
 const char* nd_device_arch(void);
@@ -399,18 +407,32 @@ int nd_step_advance(int32_t* step, int delta, nd_stream_t stream);
 int nd_copy_row_by_step(const float* table, const int32_t* step, int lo, int rows, int64_t row_floats, float* out,
                         nd_stream_t stream);
 /* x_dup | NULL: second destination of the updated images (classifier-free guidance: the unconditional half of the next
- * forward's input batch, diffusion.py:281,344 evaluate the model on the same x_t twice); not x, not x_out. */
-int nd_ddim_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
-                 float guidance_w, const float* coef, const int32_t* step, float eta,
+ * forward's input batch, diffusion.py:281,344 evaluate the model on the same x_t twice); not x, not x_out.
+ * pred_x0 | NULL: receives the step's x_0 estimate (diffusion.py:287-290 / :350-353) -- the second element of the
+ *   (sample, pred_x0) tuple Diffusion.denoising_step / ddim_denoising_step return -- laid out like x_out (ldx).
+ * flags: ND_STEP_NO_CLIP = the reference's clip_x=False (no clamp of pred_x0 to [-1, 1]); ND_STEP_PER_IMAGE = `step` points
+ *   to B words, one rescaled step index per image (the reference's `t` argument is a [B] tensor), instead of one word. */
+#define ND_STEP_NO_CLIP 1
+#define ND_STEP_PER_IMAGE 2
+int nd_ddim_step(const float* x, float* x_out, float* x_dup, float* pred_x0, int flags, int ldx, const float* eps,
+                 const float* eps_uncond, int ld_eps, float guidance_w, const float* coef, const int32_t* step, float eta,
                  const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                  uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);
-int nd_ddpm_step(const float* x, float* x_out, float* x_dup, int ldx, const float* eps, const float* eps_uncond, int ld_eps,
-                 float guidance_w, const float* coef, const int32_t* step, int var_kind,
+int nd_ddpm_step(const float* x, float* x_out, float* x_dup, float* pred_x0, int flags, int ldx, const float* eps,
+                 const float* eps_uncond, int ld_eps, float guidance_w, const float* coef, const int32_t* step, int var_kind,
                  const float* noise, int64_t noise_step_stride, uint64_t seed, const uint64_t* seed_dev,
                  uint64_t first_elem, int B, int HW, int C, nd_stream_t stream);
+/* Diffusion.get_eps_and_log_var after the model call (diffusion.py:248-264): NHWC model output [B][HW][ld_out] -> eps and
+ * log_var, both NCHW [B][C][HW]; steps = B rescaled step indices (device), coef / var_kind as for nd_ddpm_step. */
+int nd_eps_log_var(const float* model_out, int ld_out, const float* coef, const int32_t* steps, int var_kind, float* eps,
+                   float* log_var, int B, int HW, int C, nd_stream_t stream);
 /* forward diffusion q(x_t | x_0) = sqrt(abar_t) x0 + sqrt(1-abar_t) noise (diffusion.py:232-240) */
 int nd_qsample(const float* x0, const float* noise, float* out, int64_t n, float sqrt_ab, float sqrt_1mab,
                nd_stream_t stream);
+/* the same with one rescaled step index per image (Diffusion.diffusion_step takes a [B] tensor t): sqrt_ab / sqrt_1mab are
+ * device fp32 tables [S], steps B device words, per_image = C*H*W */
+int nd_qsample_steps(const float* x0, const float* noise, float* out, int B, int64_t per_image, const float* sqrt_ab,
+                     const float* sqrt_1mab, const int32_t* steps, nd_stream_t stream);
 
 /* ---- N2: image post-processing ((x+1)*127.5).clamp(0,255) -> uint8 (truncation), NHWC -> HWC bytes,
  * optional grayscale inversion 255-v (scripts/sample.py:94-100,164-171). */

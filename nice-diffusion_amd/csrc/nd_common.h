@@ -41,6 +41,14 @@ inline int ensure_max_lds(const void* kern, bool (&flags)[kMaxDevices], const ch
     return ND_OK;
 }
 
+// A library compiled with any timing-only / diagnostic macro defined (nd_variant_flags.inc lists every one the sources
+// test) reports it through nd_build_flags(): such builds give wrong results by construction and must not pass for the
+// product library.  The registration runs at load time, once per translation unit that saw the macro.
+void register_build_flag(const char* flag);
+struct BuildFlagReg {
+    explicit BuildFlagReg(const char* flag) { register_build_flag(flag); }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define ND_REQUIRE(cond, fn, msg) \
@@ -58,3 +66,11 @@ __device__ __forceinline__ float fast_silu(float v) {
 }
 
 }  // namespace nd
+
+#define ND_VF_STR(x) #x
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define ND_VARIANT_FLAG(n) namespace { const nd::BuildFlagReg nd_vf_##n(#n "=" ND_VF_STR(n)); }
+#else
+#define ND_VARIANT_FLAG(n)
+#endif
+#include "nd_variant_flags.inc"

@@ -14,6 +14,22 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// flags registered by translation units compiled with a timing-only / diagnostic macro (nd_common.h); function-local
+// storage: registration happens during static initialisation, in no particular order
+static char* build_flags_buf() {
+    static char buf[1024] = "";
+    return buf;
+}
+
+void register_build_flag(const char* flag) {
+    char* b = build_flags_buf();
+    if (strstr(b, flag)) return;
+    const size_t n = strlen(b), m = strlen(flag);
+    if (n + m + 2 >= 1024) return;
+    if (n) b[n] = ' ';
+    memcpy(b + n + (n ? 1 : 0), flag, m + 1);
+}
+
 }  // namespace nd
 
 namespace nd {
@@ -55,7 +71,14 @@ extern "C" int nd_checksum_segments(const void* const* ptrs, const int64_t* nbyt
     return nd::check_launch(fn);
 }
 
-extern "C" int nd_version(void) { return 121; }
+extern "C" int nd_version(void) { return 130; }
+
+#ifndef ND_SRC_HASH
+#define ND_SRC_HASH "unhashed"
+#endif
+extern "C" const char* nd_build_id(void) { return ND_SRC_HASH; }
+
+extern "C" const char* nd_build_flags(void) { return nd::build_flags_buf(); }
 
 extern "C" const char* nd_last_error(void) { return nd::g_err; }
 

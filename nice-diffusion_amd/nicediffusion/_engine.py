@@ -33,8 +33,9 @@ def _tune_cache_path():
 
 
 def _tune_stamp():
-    """What a file of measured choices is only valid for: the library's version and its variant tables (a choice is a
-    variant NUMBER; a rebuilt library may number its kernels differently)."""
+    """What a file of measured choices (or any other measured artefact) is only valid for: the library's SOURCE HASH
+    (nd_build_id: one changed character of any kernel source changes it -- nobody has to remember to bump a version),
+    its variant flags if it is an ablation build, its version and its variant tables (a choice is a variant NUMBER)."""
     lib = _hip.load()
     names = [lib.nd_conv_winograd_variant_name(v).decode() for v in range(lib.nd_conv_winograd_num_variants())]
     names += [lib.nd_conv_winograd_f4_variant_name(v).decode() for v in range(lib.nd_conv_winograd_f4_num_variants())]
@@ -45,7 +46,7 @@ def _tune_stamp():
     for v in range(lib.nd_conv_num_variants()):
         lib.nd_conv_variant_info(v, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         direct.append('{}x{}x{}'.format(bm.value, bn.value, nt.value))
-    return 'v{}:d{}:{}:{}'.format(lib.nd_version(), lib.nd_conv_num_variants(), ','.join(direct), '|'.join(names))
+    return 'b{}:v{}:d{}:{}:{}'.format(_hip.build_id(), lib.nd_version(), lib.nd_conv_num_variants(), ','.join(direct), '|'.join(names))
 
 
 def preload_tune_cache(path, device_index=None, override=False):
@@ -1042,9 +1043,12 @@ class UNetPlan:
             return self._embed_packed[key]
 
         def gemm(src, K, wkey, w, b, out, N, flags, label):
+            # the tile variant (and with it the order of the K sum) is the one the forward's own NR = NI launch selects, also
+            # when embed_table runs the same GEMM on steps * NI rows: a table row is then bit for bit what the forward leaves
+            # in e_all, and a chain resumed in parts equals the chain run in one piece
+            var = lib.nd_conv_select_variant(1, 1, self.NI, N, 1, flags, 0)
             args = [src.data_ptr(), K, K, None, 0, 0, packed(wkey, w).data_ptr(), b.detach().data_ptr(),
-                    None, 0, None, 0, out, N, 1, 1, NR, N, 1, flags, -1, None, None, 0]
-            var = lib.nd_conv_select_variant(1, 1, NR, N, 1, flags, 0)
+                    None, 0, None, 0, out, N, 1, 1, NR, N, 1, flags, var, None, None, 0]
             self._emit(lib.nd_conv_nhwc, args, label, flops=2 * NR * N * K, variant=('direct', var), ksize=1)
             self.flops += 2 * NR * N * K
 
@@ -1063,12 +1067,18 @@ class UNetPlan:
         return [temb, h1, emb, semb]
 
     def embed_table_bytes(self, rows):
-        return 4 * rows * self.NI * self.e_ld
+        """Table + the K1/K2 scratch rows of ``embed_table`` for a chain of ``rows`` steps."""
+        mc = self.model.model_channels
+        return 4 * rows * self.NI * (self.e_ld + 13 * mc) + 16 * rows * self.NI
+
+    def drop_embed_table(self):
+        """Release the chain table (and its scratch); a graph captured on it must not be replayed afterwards."""
+        self._etab = None
 
     def embed_table(self, t_rows):
         """K1/K2 of a whole chain at once: ``t_rows`` (int64 [S], the model timestep of every step index the chain will
-        visit) and the labels in ``y_in`` -> fp32 table [S][NI * e_ld] whose row r is exactly what the forward's own K1/K2
-        launches would leave in ``e_all`` at t_rows[r] (same kernels on S * NI rows).  The step body then copies one row
+        visit) and the labels in ``y_in`` -> fp32 table [S][NI * e_ld] whose row r is bit for bit what the forward's own K1/K2
+        launches would leave in ``e_all`` at t_rows[r] (the same kernels AND tile variants on S * NI rows).  The step body then copies one row
         (nd_copy_row_by_step) and calls run(skip_embed=True).  Launched on the current stream; storage and launch list
         are cached per S, so a captured graph that reads the table stays valid across calls."""
         self._require_current_device()

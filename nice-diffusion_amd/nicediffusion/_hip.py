@@ -23,6 +23,8 @@ VAR_FIXED = 0
 VAR_LEARNED = 1
 VAR_LEARNED_INTERP = 2
 COEF_COLS = 8
+STEP_NO_CLIP = 1
+STEP_PER_IMAGE = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -88,8 +90,10 @@ SIGNATURES = {
     'nd_conv3x3_taps_gather_nhwc': [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_groupnorm_apply_coeffs_nhwc': [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'nd_copy_row_by_step': [_vp, _vp, _i, _i, _i64, _vp, _vp],
-    'nd_ddim_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
-    'nd_ddpm_step': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_ddim_step': [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_ddpm_step': [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i64, _u64, _vp, _u64, _i, _i, _i, _vp],
+    'nd_eps_log_var': [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    'nd_qsample_steps': [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp],
     'nd_checksum_segments': [_vp, _vp, _i, _vp, _vp],
     'nd_qsample': [_vp, _vp, _vp, _i64, _f, _f, _vp],
     'nd_to_uint8_hwc': [_vp, _i, _vp, _i, _i, _i, _i, _vp],
@@ -126,6 +130,8 @@ _SPECIAL = {
     'nd_conv_select_variant': ([_i, _i, _i, _i, _i, _i, _i], _i),
     'nd_conv_variant_info': ([_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     'nd_last_error': ([], ctypes.c_char_p),
+    'nd_build_id': ([], ctypes.c_char_p),
+    'nd_build_flags': ([], ctypes.c_char_p),
     'nd_device_arch': ([], ctypes.c_char_p),
 }
 EXPORTS = sorted(list(SIGNATURES) + list(_SPECIAL))
@@ -165,8 +171,32 @@ def load():
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = restype
+    flags = L.nd_build_flags().decode()
+    if flags and os.environ.get('ND_ALLOW_ABLATION') != '1':
+        raise NdHipError('{} was compiled with timing-only / diagnostic macros ({}): such a build computes wrong results by '
+                         'construction; set ND_ALLOW_ABLATION=1 to load it for a measurement'.format(_LIB_PATH, flags))
     _LIB = L
     return L
+
+
+def build_id():
+    """Source hash of the loaded library (+ its variant flags, if any): the stamp of every measured artefact."""
+    L = load()
+    flags = L.nd_build_flags().decode()
+    return L.nd_build_id().decode() + ('+' + flags.replace(' ', ',') if flags else '')
+
+
+def source_hash(root=None):
+    """What the Makefile would stamp a library built from the sources in the tree with (nd_build_id of a current build)."""
+    import glob
+    import hashlib
+    pkg = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(pkg, 'csrc', '*.hip')) + glob.glob(os.path.join(pkg, 'csrc', '*.h')) + \
+        glob.glob(os.path.join(pkg, 'csrc', '*.inc')) + [os.path.join(pkg, '..', 'include', 'nd_hip.h')]
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def last_error():

@@ -183,6 +183,164 @@ class Diffusion:
                                               torch.cuda.current_stream().cuda_stream), 'nd_qsample')
         return out
 
+    # ---------------------------------------------------------------------------------------------- per-step surface
+    # The reference's public per-step methods (diffusion.py:232-369), for callers that walk the chain themselves (the usual
+    # way to show the pred_x0 progression).  ``t`` is what the reference's loop passes (diffusion.py:216): a [B] tensor of
+    # RESCALED step indices, float or integer, one per image -- the rows may differ.  One call = one eager UNet plan run
+    # + one fused sampler launch; ``denoise`` remains the fast path (device step word, captured graph).
+    def _step_indices(self, t, B):
+        """[B] int32 device tensor of rescaled indices from the reference's float / long ``t``; a python int or 0-d tensor
+        broadcasts.  torch.gather raises on an index outside the table (diffusion.py:491): so does this."""
+        t = torch.as_tensor(t)
+        if t.dim() == 0:
+            t = t.reshape(1).expand(B)
+        assert t.shape[0] == B, 'one step index per image'
+        ti = t.to(self.device).long()
+        lo, hi = (int(v) for v in torch.aminmax(ti))
+        if lo < 0 or hi >= len(self.betas):
+            raise IndexError('step index out of range: got [{}, {}], the chain has {} steps'.format(lo, hi, len(self.betas)))
+        return ti.to(torch.int32).contiguous()
+
+    def _step_tables(self):
+        """Device copies of the per-step tables the per-step methods gather from (refreshed when the schedule or the
+        variance type changed)."""
+        key = (self.sampling_var_type, self.betas.tobytes())
+        st = self.__dict__.get('_step_tabs')
+        if st is None or st['key'] != key:
+            dev = self.device
+            st = dict(key=key, coef=self.coefficient_table().to(dev).contiguous(),
+                      sa=torch.from_numpy(self.sqrt_alphas_cumprod).float().to(dev).contiguous(),
+                      sb=torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).float().to(dev).contiguous(),
+                      tmap=self.timestep_map.to(dev).contiguous())
+            self.__dict__['_step_tabs'] = st
+        return st
+
+    @torch.no_grad()
+    def diffusion_step(self, x_0, t, noise=None):
+        """Sample q(x_t | x_0) with one step index per image (reference diffusion.py:232-240)."""
+        x_0 = x_0.to(self.device).float().contiguous()
+        _hip.require_device(x_0, 'x_0')
+        B = x_0.shape[0]
+        steps = self._step_indices(t, B)
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        noise = noise.to(self.device).float().contiguous()
+        assert noise.shape == x_0.shape, 'noise must have the shape of x_0'
+        tabs = self._step_tables()
+        out = torch.empty_like(x_0)
+        with torch.cuda.device(x_0.device):
+            _hip.check(_hip.load().nd_qsample_steps(x_0.data_ptr(), noise.data_ptr(), out.data_ptr(), B, x_0[0].numel(),
+                                                    tabs['sa'].data_ptr(), tabs['sb'].data_ptr(), steps.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), 'nd_qsample_steps')
+        return out
+
+    def _model_eps(self, x_t, steps, kwargs, guided):
+        """Stage x_t / labels / timesteps into the plan of the forward batch (2B under classifier-free guidance: the
+        conditional rows, then the same images with the null class, diffusion.py:280-281,343-344) and run it."""
+        model = self.model
+        y = (kwargs or {}).get('y')
+        assert (y is not None) == model.conditional, 'pass label iff model is class-conditional'
+        assert x_t.shape[2] == model.resolution and x_t.shape[3] == model.resolution, \
+            'incorrect resolution: {}'.format(x_t.shape[2:])
+        if self.guidance == 'classifier':
+            raise NotImplementedError('classifier guidance needs autograd through a classifier (out of scope)')
+        if model.conditional:
+            model._check_labels(y)
+        B = x_t.shape[0]
+        NI = 2 * B if guided else B
+        plan = model._plan(NI)
+        lib = plan.lib
+        C, HW = model.in_channels, model.resolution ** 2
+        s = torch.cuda.current_stream().cuda_stream
+        _hip.check(lib.nd_nchw_to_nhwc(x_t.data_ptr(), plan.x_in.data_ptr(), B, C, HW, plan.Cin_p, s), 'nd_nchw_to_nhwc')
+        tm = self._step_tables()['tmap'][steps.long()]
+        plan.t_in[:B].copy_(tm)
+        if model.conditional:
+            plan.y_in[:B].copy_(y.to(self.device).to(torch.int64))
+        if guided:
+            n = B * HW * plan.Cin_p
+            plan.x_in[n:2 * n].copy_(plan.x_in[:n])
+            plan.t_in[B:].copy_(tm)
+            plan.y_in[B:].zero_()
+        plan.run()
+        return plan
+
+    @torch.no_grad()
+    def get_eps_and_log_var(self, x_t, t, kwargs):
+        """(eps_pred, log_var) of the model at (x_t, t), each [B, C, R, R] (reference diffusion.py:242-264; no guidance
+        mix here, as in the reference)."""
+        x_t = x_t.to(self.device).float().contiguous()
+        _hip.require_device(x_t, 'x_t')
+        B, C, R = x_t.shape[0], self.model.in_channels, self.model.resolution
+        with torch.cuda.device(x_t.device):
+            steps = self._step_indices(t, B)
+            plan = self._model_eps(x_t, steps, kwargs, False)
+            eps = torch.empty(B, C, R, R, dtype=torch.float32, device=self.device)
+            log_var = torch.empty_like(eps)
+            _hip.check(plan.lib.nd_eps_log_var(plan.out.data_ptr(), plan.Cout_p, self._step_tables()['coef'].data_ptr(),
+                                               steps.data_ptr(), self._var_kind(), eps.data_ptr(), log_var.data_ptr(), B,
+                                               R * R, C, torch.cuda.current_stream().cuda_stream), 'nd_eps_log_var')
+        return eps, log_var
+
+    def _public_step(self, ddim, x_t, t, kwargs, clip_x, noise):
+        x_t = x_t.to(self.device).float().contiguous()
+        _hip.require_device(x_t, 'x_t')
+        model = self.model
+        B, C, R = x_t.shape[0], model.in_channels, model.resolution
+        HW = R * R
+        cfg = self.guidance == 'classifier_free'
+        if ddim:
+            assert self.ddim_eta is not None, 'please supply eta if you want to use ddim'
+        with torch.cuda.device(x_t.device):
+            steps = self._step_indices(t, B)
+            plan = self._model_eps(x_t, steps, kwargs, cfg)
+            lib = plan.lib
+            s = torch.cuda.current_stream().cuda_stream
+            n = B * HW * plan.Cin_p
+            sample = torch.empty(n, dtype=torch.float32, device=self.device)
+            pred = torch.empty(n, dtype=torch.float32, device=self.device)
+            noise_ptr = None
+            if noise is not None:
+                nz = torch.empty(n, dtype=torch.float32, device=self.device)
+                nc = noise.to(self.device).float().contiguous()
+                assert tuple(nc.shape) == (B, C, R, R), 'noise must be [B, C, R, R]'
+                _hip.check(lib.nd_nchw_to_nhwc(nc.data_ptr(), nz.data_ptr(), B, C, HW, plan.Cin_p, s), 'nd_nchw_to_nhwc')
+                noise_ptr = nz.data_ptr()
+            seed = self.seed
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            flags = _hip.STEP_PER_IMAGE | (0 if clip_x else _hip.STEP_NO_CLIP)
+            eps_u = plan.out.data_ptr() + 4 * B * HW * plan.Cout_p if cfg else None
+            w = float(self.strength) if cfg else 0.0
+            coef = self._step_tables()['coef'].data_ptr()
+            first_elem = int(self.first_row) * HW * C
+            if ddim:
+                rc = lib.nd_ddim_step(plan.x_in.data_ptr(), sample.data_ptr(), None, pred.data_ptr(), flags, plan.Cin_p,
+                                      plan.out.data_ptr(), eps_u, plan.Cout_p, w, coef, steps.data_ptr(), float(self.ddim_eta),
+                                      noise_ptr, 0, seed, None, first_elem, B, HW, C, s)
+            else:
+                rc = lib.nd_ddpm_step(plan.x_in.data_ptr(), sample.data_ptr(), None, pred.data_ptr(), flags, plan.Cin_p,
+                                      plan.out.data_ptr(), eps_u, plan.Cout_p, w, coef, steps.data_ptr(), self._var_kind(),
+                                      noise_ptr, 0, seed, None, first_elem, B, HW, C, s)
+            _hip.check(rc, 'sampler step')
+            outs = []
+            for buf in (sample, pred):
+                o = torch.empty(B, C, R, R, dtype=torch.float32, device=self.device)
+                _hip.check(lib.nd_nhwc_to_nchw(buf.data_ptr(), o.data_ptr(), B, C, HW, plan.Cin_p, s), 'nd_nhwc_to_nchw')
+                outs.append(o)
+        return outs[0], outs[1]
+
+    @torch.no_grad()
+    def denoising_step(self, x_t, t, kwargs=None, clip_x=True, noise=None):
+        """One DDPM step p(x_{t-1} | x_t): returns ``(sample, pred_x0)`` (reference diffusion.py:266-316).  ``noise``
+        (extension, parity tests): the N(0,1) draw to use instead of in-kernel Philox noise."""
+        return self._public_step(False, x_t, t, kwargs, clip_x, noise)
+
+    @torch.no_grad()
+    def ddim_denoising_step(self, x_t, t, kwargs=None, clip_x=True, noise=None):
+        """One DDIM step: returns ``(sample, pred_x0)`` (reference diffusion.py:318-369)."""
+        return self._public_step(True, x_t, t, kwargs, clip_x, noise)
+
     # ---------------------------------------------------------------------------------------------- reverse process
     @torch.no_grad()
     def denoise(self, x=None, kwargs=None, start_step=None, steps_to_do=None, batch_size=1, ema_params=None,
@@ -212,7 +370,7 @@ class Diffusion:
                 original[name] = p.data
                 p.data = ema_params[name].to(self.device)
             model.invalidate_plans()    # plans hold repacked copies of the weights that were just swapped out
-            self._loops = {}
+            self.release()
         try:
             if start_step is None:
                 start_step = self.rescaled_num_steps
@@ -233,7 +391,15 @@ class Diffusion:
                 for name, p in model.named_parameters():
                     p.data = original[name]
                 model.invalidate_plans()
-                self._loops = {}
+                self.release()
+
+    def release(self):
+        """Drop the captured graph, the loop's device words and the chain's K1/K2 table (up to ND_EMBED_TABLE_MAX_GB of
+        device memory held between ``denoise`` calls so that the graph can be replayed)."""
+        for st in self._loops.values():
+            st['graph'] = None
+            st['plan'].drop_embed_table()
+        self._loops = {}
 
     def _run_loop(self, x, y, steps_to_do, progress, noise, trace, first_index=None):
         model = self.model
@@ -255,6 +421,7 @@ class Diffusion:
             st = dict(plan=plan, coef=None, coef_key=None, tmap=self.timestep_map.to(dev).contiguous(),
                       step=torch.zeros(1, dtype=torch.int32, device=dev),
                       seed=torch.zeros(1, dtype=torch.int64, device=dev), graph=None, graph_key=None, noise=None)
+            self.release()
             self._loops = {key: st}
         # the coefficient rows depend on the schedule AND on the variance type ('large' / 'small' share a kernel
         # variance kind but not column 6): refresh them whenever either changed since they were uploaded
@@ -309,13 +476,25 @@ class Diffusion:
         st['step'].fill_(first)
 
         # K1/K2 depend on (t, y) only: evaluated for every step of this chain in one batched pass before the loop
-        # (model.py:346-352,197); the step body copies its row by the device step word.  ND_HOIST_EMBED=0, or a table
-        # over ND_EMBED_TABLE_MAX_GB (default 8), keeps them inside the forward
+        # (model.py:346-352,197); the step body copies its row by the device step word.  The table is an optimisation worth
+        # ~0.2 % of a chain, so it never gets to fail one: it is kept inside ND_EMBED_TABLE_MAX_GB (default 4) AND a tenth
+        # of the memory free on the device right now, and an allocation failure falls back to K1/K2 inside the forward
+        # (ND_HOIST_EMBED=0 keeps them there always).  It lives as long as the captured graph that reads it: dropped with
+        # the loop state (another plan, EMA swap, ``release()``)
         lo = first - steps_to_do + 1
         etab = None
-        if (plan.e_all is not None and os.environ.get('ND_HOIST_EMBED', '1') != '0' and steps_to_do > 1 and (NI * plan.e_ld) % 4 == 0 and
-                plan.embed_table_bytes(steps_to_do) <= float(os.environ.get('ND_EMBED_TABLE_MAX_GB', '8')) * 2 ** 30):
-            etab = plan.embed_table(st['tmap'][lo:first + 1])
+        if (plan.e_all is not None and os.environ.get('ND_HOIST_EMBED', '1') != '0' and steps_to_do > 1 and (NI * plan.e_ld) % 4 == 0):
+            cap = float(os.environ.get('ND_EMBED_TABLE_MAX_GB', '4')) * 2 ** 30
+            have = plan._etab is not None and plan._etab['S'] == steps_to_do
+            if not have:
+                cap = min(cap, 0.1 * torch.cuda.mem_get_info(dev)[0])
+            if plan.embed_table_bytes(steps_to_do) <= cap:
+                try:
+                    etab = plan.embed_table(st['tmap'][lo:first + 1])
+                except torch.cuda.OutOfMemoryError:
+                    plan.drop_embed_table()
+                    st['graph'] = None
+                    etab = None
         row_floats = NI * plan.e_ld
 
         eps_ptr = plan.out.data_ptr()
@@ -336,10 +515,10 @@ class Diffusion:
                            'nd_fill_timestep')
                 plan.run()
             if self.use_ddim:
-                rc = lib.nd_ddim_step(xp, xp, xdup, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                rc = lib.nd_ddim_step(xp, xp, xdup, None, 0, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
                                       st['step'].data_ptr(), eta, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             else:
-                rc = lib.nd_ddpm_step(xp, xp, xdup, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
+                rc = lib.nd_ddpm_step(xp, xp, xdup, None, 0, plan.Cin_p, eps_ptr, eps_u_ptr, plan.Cout_p, w, st['coef'].data_ptr(),
                                       st['step'].data_ptr(), var_kind, noise_ptr, noise_stride, 0, seed_ptr, first_elem, B, HW, C, s)
             _hip.check(rc, 'sampler step')
             _hip.check(lib.nd_step_advance(st['step'].data_ptr(), -1, s), 'nd_step_advance')

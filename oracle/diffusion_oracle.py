@@ -111,16 +111,16 @@ class SamplerOracle:
             eps = (1 + self.w) * eps - self.w * base
         return eps, v
 
-    def _pred_x0(self, x, eps, t):                                      # :287-290 / :350-353
+    def _pred_x0(self, x, eps, t, clip_x=True):                         # :287-290 / :350-353
         s = self.s
         p = _ex(s.sqrt_reciprocal_alphas_cumprod, t) * x - _ex(s.sqrt_reciprocal_alphas_minus_one_cumprod, t) * eps
-        return torch.clamp(p, -1, 1)
+        return torch.clamp(p, -1, 1) if clip_x else p
 
-    def ddim_step(self, x, t, y=None, noise=None):
-        """diffusion.py:318-369.  ``t`` is the rescaled index (python int)."""
+    def ddim_step(self, x, t, y=None, noise=None, clip_x=True):
+        """diffusion.py:318-369.  ``t`` is the rescaled index (python int).  Returns (sample, pred_x0)."""
         s = self.s
         eps, _ = self._eps(x, t, y)
-        x0 = self._pred_x0(x, eps, t)
+        x0 = self._pred_x0(x, eps, t, clip_x)
         ab = _ex(s.alphas_cumprod, t)
         abp = _ex(s.alphas_cumprod_prev, t)
         var = self.eta ** 2 * (1.0 - abp) * (1.0 - ab / abp) / (1.0 - ab)
@@ -130,22 +130,35 @@ class SamplerOracle:
         mask = 0.0 if t == 0 else 1.0
         return (mean + mask * torch.sqrt(var) * noise).float(), x0
 
-    def ddpm_step(self, x, t, y=None, noise=None):
-        """diffusion.py:266-316 with get_eps_and_log_var :242-264."""
+    def _log_var(self, v, t):                                           # :248-261
         s = self.s
-        eps, v = self._eps(x, t, y)
         if self.var_type == 'learned':
-            log_var = v
-        elif self.var_type == 'learned_interpolation':
+            return v
+        if self.var_type == 'learned_interpolation':
             min_log = _ex(s.log_posterior_var_clipped, t)
             max_log = _ex(np.log(s.betas), t)
             frac = (v + 1) / 2
-            log_var = frac * max_log + (1 - frac) * min_log
-        elif self.var_type == 'large':
-            log_var = _ex(np.log(np.append(s.posterior_variance[1], s.betas[1:])), t)
-        else:
-            log_var = _ex(np.log(np.maximum(s.posterior_variance, 1e-20)), t)
-        x0 = self._pred_x0(x, eps, t)
+            return frac * max_log + (1 - frac) * min_log
+        if self.var_type == 'large':
+            return _ex(np.log(np.append(s.posterior_variance[1], s.betas[1:])), t)
+        return _ex(np.log(np.maximum(s.posterior_variance, 1e-20)), t)
+
+    def eps_and_log_var(self, x, t, y=None):
+        """diffusion.py:242-264: the model's eps (NO guidance mix) and the log-variance, the latter broadcast to x's shape."""
+        B = x.shape[0]
+        out = self.f(x, torch.full((B,), int(self.s.timestep_map[t]), dtype=torch.long), y)
+        v = None
+        if self.learned:
+            out, v = torch.split(out, out.shape[1] // 2, dim=1)
+        lv = self._log_var(v, t)
+        return out, (lv if self.learned else lv.expand(x.shape))
+
+    def ddpm_step(self, x, t, y=None, noise=None, clip_x=True):
+        """diffusion.py:266-316 with get_eps_and_log_var :242-264.  Returns (sample, pred_x0)."""
+        s = self.s
+        eps, v = self._eps(x, t, y)
+        log_var = self._log_var(v, t)
+        x0 = self._pred_x0(x, eps, t, clip_x)
         mean = _ex(s.posterior_mean_coef_x0, t) * x0 + _ex(s.posterior_mean_coef_xt, t) * x
         if noise is None:
             noise = torch.zeros_like(x)

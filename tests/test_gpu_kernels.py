@@ -597,17 +597,17 @@ def test_sampler_step_kernels(kind):
         dp = dup.data_ptr() if cfg else None
         eu = eud.data_ptr() if cfg else None
         if ddim:
-            rc = lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), dp, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+            rc = lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), dp, None, 0, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
                                     step.data_ptr(), eta, nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4, 0, None, 0, B,
                                     R * R, C, st())
         else:
-            rc = lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), dp, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
+            rc = lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), dp, None, 0, 4, ed.data_ptr(), eu, 8, 0.8, coef.data_ptr(),
                                     step.data_ptr(), d._var_kind(), nd_.data_ptr() - 4 * t * B * R * R * 4, B * R * R * 4,
                                     0, None, 0, B, R * R, C, st())
         _hip.check(rc)
         if cfg:
             assert torch.equal(dup, out)
-            assert lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), out.data_ptr(), 4, ed.data_ptr(), eu, 8, 0.8,
+            assert lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), out.data_ptr(), None, 0, 4, ed.data_ptr(), eu, 8, 0.8,
                                       coef.data_ptr(), step.data_ptr(), 0.0, None, 0, 0, None, 0, B, R * R, C, st()) != 0
         got = torch.empty(B, C, R, R, device=DEV)
         _hip.check(lib().nd_nhwc_to_nchw(out.data_ptr(), got.data_ptr(), B, C, R * R, 4, st()))
@@ -633,7 +633,7 @@ def test_philox_noise_is_standard_normal():
     outs = []
     for seed in (1, 2):
         out = torch.zeros(n, device=DEV)
-        _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
+        _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, None, 0, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
                                       step.data_ptr(), _hip.VAR_FIXED, None, 0, seed, None, 0, B, R * R, C, st()))
         outs.append(out.view(-1, 4)[:, :3].cpu())
     z = outs[0].flatten()
@@ -644,7 +644,7 @@ def test_philox_noise_is_standard_normal():
     # the seed may also come from a device word (what the captured loop uses): same numbers as the by-value seed
     word = torch.tensor([2], dtype=torch.int64, device=DEV)
     out = torch.zeros(n, device=DEV)
-    _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
+    _hip.check(lib().nd_ddpm_step(x.data_ptr(), out.data_ptr(), None, None, 0, 4, eps.data_ptr(), None, 8, 0.0, coef.data_ptr(),
                                   step.data_ptr(), _hip.VAR_FIXED, None, 0, 777, word.data_ptr(), 0, B, R * R, C, st()))
     assert torch.equal(out.view(-1, 4)[:, :3].cpu(), outs[1])
 
@@ -688,10 +688,10 @@ def test_sampler_generic_form_matches_image_form(ddim):
         xd, ed = xd.to(DEV), ed.to(DEV)
         out = torch.zeros_like(xd)
         if ddim:
-            _hip.check(lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), None, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+            _hip.check(lib().nd_ddim_step(xd.data_ptr(), out.data_ptr(), None, None, 0, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
                                           step.data_ptr(), 0.6, None, 0, 99, None, 0, B, HW, C, st()))
         else:
-            _hip.check(lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), None, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
+            _hip.check(lib().nd_ddpm_step(xd.data_ptr(), out.data_ptr(), None, None, 0, ldx, ed.data_ptr(), None, lde, 0.0, coef.data_ptr(),
                                           step.data_ptr(), _hip.VAR_LEARNED_INTERP, None, 0, 99, None, 0, B, HW, C, st()))
         outs.append(out[..., :C].cpu())
     assert torch.isfinite(outs[0]).all() and (outs[0] - x).abs().max().item() > 1e-3

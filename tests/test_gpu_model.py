@@ -177,6 +177,78 @@ def test_sampler_loops_vs_reference_golden(golden_dir, name):
     assert np.abs(out_g.cpu().numpy() - traj[-1]).max() < 1e-3
 
 
+@pytest.mark.parametrize('name', sorted(SAMPLER_CASES))
+def test_public_per_step_methods_vs_reference_golden(golden_dir, name):
+    """The reference's public per-step surface (diffusion.py:232-369), as a caller that walks the chain itself uses it:
+    ``ddim_denoising_step`` / ``denoising_step(x_t, t, kwargs, clip_x)`` return ``(sample, pred_x0)``, ``t`` is the float32 [B]
+    tensor of rescaled indices the reference's loop passes (diffusion.py:216).  Teacher-forced along the reference's own
+    trajectory (tests/golden/sampler_steps_<case>.npz, tools/gen_golden.py gen_sampler_steps): every step's sample and
+    pred_x0 with and without the clamp, one call with a DIFFERENT index per image, get_eps_and_log_var, and diffusion_step
+    with per-image indices.  pred_x0 = c_t x - c'_t eps with c'_t up to 404 at the head of these 10-step chains, so its bound
+    is the eps bound scaled by c'_t; everything else is asserted at 1e-4 (relative to the tensor's scale where clip_x=False
+    lets it reach 400)."""
+    g = np.load(os.path.join(golden_dir, 'sampler_{}.npz'.format(name)))
+    gs = np.load(os.path.join(golden_dir, 'sampler_steps_{}.npz'.format(name)))
+    case = SAMPLER_CASES[name]
+    cfg = dict(TINY_CFGS[case['cfg']])
+    learned = case['var'] in ('learned', 'learned_interpolation')
+    cfg['out_channels'] = cfg['in_channels'] * (2 if learned else 1)
+    m = build(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+    S = case['S']
+    d = Diffusion(m, 1000, S, case['var'], 'simple', beta_schedule=case['sched'],
+                  guidance_method=case.get('guidance'), guidance_strength=case.get('w'), use_ddim=case['ddim'],
+                  ddim_eta=case.get('eta'), device=DEV)
+    kwargs = {'y': torch.from_numpy(g['y']).to(DEV)} if 'y' in g.files else {}
+    noises, traj, xT = torch.from_numpy(g['noises']), g['traj'], torch.from_numpy(g['xT'])
+    B = xT.shape[0]
+    step = d.ddim_denoising_step if case['ddim'] else d.denoising_step
+    rel = lambda a, b: float(np.abs(a.cpu().numpy() - b).max() / max(1.0, np.abs(b).max()))
+    cm1 = d.sqrt_reciprocal_alphas_minus_one_cumprod
+    ptol = lambda t: 2e-5 + 4e-6 * float(cm1[t])            # eps within 4e-6 of the reference's
+    worst = dict(sample=0.0, pred=0.0, noclip=0.0)
+    for i, t in enumerate(reversed(range(S))):
+        xt = xT if i == 0 else torch.from_numpy(traj[i - 1])
+        ts = (t * torch.ones(B)).to(DEV)                     # float32 [B], as diffusion.py:216 builds it
+        smp, p0 = step(xt.to(DEV), ts, kwargs, noise=noises[t])
+        assert smp.shape == p0.shape == xt.shape and smp.dtype == torch.float32
+        e_s, e_p = rel(smp, traj[i]), float(np.abs(p0.cpu().numpy() - gs['pred_x0'][i]).max())
+        assert e_s < 1e-4 and e_p < ptol(t), (name, t, e_s, e_p, ptol(t))
+        a, b = step(xt.to(DEV), ts, kwargs, clip_x=False, noise=noises[t])
+        e_n = max(rel(a, gs['noclip_sample'][i]), rel(b, gs['noclip_pred_x0'][i]))
+        assert e_n < 1e-4, (name, t, e_n)
+        worst = dict(sample=max(worst['sample'], e_s), pred=max(worst['pred'], e_p / ptol(t)), noclip=max(worst['noclip'], e_n))
+        # the loop's own step at this index gives the same sample bit for bit (same kernel arithmetic, EX = false form)
+        lp = d.denoise(x=xt, kwargs=kwargs or None, steps_to_do=1, first_index=t, batch_size=B, progress=False, noise=noises)
+        assert torch.equal(lp, smp), (name, t)
+    assert float(np.abs(gs['noclip_pred_x0']).max()) > 50          # the clamp matters in these fixtures
+    # one index per image: [S - 1, 0] (the second image takes the masked t = 0 step)
+    tm = torch.from_numpy(gs['t_mixed']).to(DEV)
+    smp, p0 = step(torch.from_numpy(gs['mixed_x']).to(DEV), tm, kwargs, noise=noises[0])
+    assert rel(smp, gs['mixed_sample']) < 1e-4
+    for b_, t in enumerate(int(v) for v in gs['t_mixed']):
+        assert float(np.abs(p0[b_].cpu().numpy() - gs['mixed_pred_x0'][b_]).max()) < ptol(t), (name, t)
+    # a long tensor and a python int are accepted like the float tensor; an index outside the chain raises
+    s2, _ = step(torch.from_numpy(gs['mixed_x']).to(DEV), tm.long(), kwargs, noise=noises[0])
+    assert torch.equal(s2, smp)
+    with pytest.raises(IndexError):
+        step(xT.to(DEV), torch.full((B,), float(S)), kwargs)
+    # get_eps_and_log_var: the model's eps (no guidance mix) and the log-variance, [B, C, R, R] each
+    for k, t in enumerate(int(v) for v in gs['eps_indices']):
+        e, lv = d.get_eps_and_log_var(torch.from_numpy(gs['mixed_x']).to(DEV), (t * torch.ones(B)).to(DEV), kwargs)
+        assert e.shape == lv.shape == xT.shape
+        assert rel(e, gs['eps'][k]) < 1e-4 and rel(lv, gs['log_var'][k]) < 1e-4, (name, t)
+    # diffusion_step with one index per image
+    q = d.diffusion_step(torch.tanh(xT).to(DEV), tm, noise=noises[1].to(DEV))
+    assert rel(q, gs['q_mixed']) < 1e-6
+    # without an injected draw the step uses in-kernel Philox noise: finite, and seed-reproducible
+    d.seed = 11
+    r1, _ = step(xT.to(DEV), ((S - 1) * torch.ones(B)).to(DEV), kwargs)
+    r2, _ = step(xT.to(DEV), ((S - 1) * torch.ones(B)).to(DEV), kwargs)
+    assert torch.isfinite(r1).all() and torch.equal(r1, r2)
+    print('per-step surface {}: sample {:.2e}, pred_x0 {:.2f} of its bound, clip_x=False {:.2e} (relative)'.format(
+        name, worst['sample'], worst['pred'], worst['noclip']))
+
+
 def test_config1_emnist_ddim50_end_to_end(golden_dir):
     """BASELINE configs[0] on the GPU vs the reference's CPU output (x_T, labels, weights from the same seeds)."""
     g = np.load(os.path.join(golden_dir, 'config1_emnist_ddim50.npz'))
@@ -426,9 +498,11 @@ def test_one_captured_graph_serves_every_seed():
 @pytest.mark.parametrize('cfg_name,guided', [('adagn_updown', True), ('adagn_updown', False), ('plain_convres_legacy', False)])
 def test_embedding_rows_hoisted_out_of_the_loop(monkeypatch, cfg_name, guided):
     """K1/K2 of every step evaluated before the loop (plan.embed_table + nd_copy_row_by_step) against the same chain with
-    the timestep MLP inside every forward (ND_HOIST_EMBED=0): the table's rows are the forward's own e_all (same kernels
-    on S * NI rows; a different tile may order the K sum differently, hence 2e-6 rather than bit equality), and the
-    classifier-free batch's second copy of x_t now comes from the sampler kernel."""
+    the timestep MLP inside every forward (ND_HOIST_EMBED=0): the table's rows are the forward's own e_all BIT FOR BIT (the
+    same kernels AND the tile variants the forward's NR = NI launches select, on S * NI rows), so the two chains -- whole and
+    resumed in the middle -- are torch.equal; the classifier-free batch's second copy of x_t comes from the sampler kernel.
+    Then the table's memory guard: an allocation failure inside embed_table falls back to K1/K2 in the forward (same bits),
+    and release() drops the table."""
     name = cfg_name
     m = build(TINY_CFGS[name])
     S = 6
@@ -448,13 +522,30 @@ def test_embedding_rows_hoisted_out_of_the_loop(monkeypatch, cfg_name, guided):
         plan.t_in.fill_(int(d.timestep_map[r]))
         plan.run()
         torch.cuda.synchronize()
-        assert (tab[r] - plan.e_all).abs().max().item() <= 2e-6 * max(1.0, plan.e_all.abs().max().item())
+        assert torch.equal(tab[r], plan.e_all)
     part = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False, steps_to_do=4, first_index=4)      # lo = 1
+    # an allocation failure while the table is built must not fail the chain: K1/K2 stay in the forward
+    d.release()
+    assert plan._etab is None
+    real_table = type(plan).embed_table
+
+    def oom(self, t_rows):
+        raise torch.cuda.OutOfMemoryError('simulated')
+    monkeypatch.setattr(type(plan), 'embed_table', oom)
+    fell_back = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False)
+    assert plan._etab is None and torch.equal(fell_back, on)
+    monkeypatch.setattr(type(plan), 'embed_table', real_table)
+    # a table over the cap (here: cap 0) is not built either
+    monkeypatch.setenv('ND_EMBED_TABLE_MAX_GB', '0')
+    d.release()
+    capped = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False)
+    assert plan._etab is None and torch.equal(capped, on)
+    monkeypatch.delenv('ND_EMBED_TABLE_MAX_GB')
     monkeypatch.setenv('ND_HOIST_EMBED', '0')
-    d._loops = {}
+    d.release()
     off = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False)
     part_off = d.denoise(x=xT, kwargs=kw, batch_size=3, progress=False, steps_to_do=4, first_index=4)
-    assert (on - off).abs().max().item() < 2e-5 and (part - part_off).abs().max().item() < 2e-5
+    assert torch.equal(on, off) and torch.equal(part, part_off)
     assert torch.isfinite(on).all()
 
 
@@ -611,11 +702,17 @@ def test_bench_one_rank_over_rccl():
 
 
 def _preload_committed_tune_cache(workload):
-    """The plan bench.py times is built from profiles/tune_cache_<workload>.json when that file matches the library: the
-    full-size tests pin THAT plan.  (Without a matching file both tune on the box, per layer, as before.)"""
+    """The plan bench.py times is built from profiles/tune_cache_<workload>.json: the full-size tests pin THAT plan, so the
+    file must be taken -- every choice of it.  A file stamped by another library build (preload returns 0; the plan would
+    then be tuned on the box and the test would no longer check what BENCH times) fails here."""
+    import json
     from nicediffusion import _engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return _engine.preload_tune_cache(os.path.join(root, 'profiles', 'tune_cache_{}.json'.format(workload)), override=True)
+    path = os.path.join(root, 'profiles', 'tune_cache_{}.json'.format(workload))
+    n = _engine.preload_tune_cache(path, override=True)
+    assert n == len(json.load(open(path))) - 1 and n > 20, \
+        'profiles/tune_cache_{}.json was not taken ({} choices): regenerate it for this build (tools/tune_all.sh)'.format(workload, n)
+    return n
 
 
 def test_full_size_config2_plan_vs_reference_rows_and_oracle(golden_dir):
@@ -676,7 +773,9 @@ def test_full_size_config2_plan_vs_reference_rows_and_oracle(golden_dir):
     print('config2 B=64 plan: forward rows vs reference {:.2e}, vs oracle {:.2e}; DDIM step vs reference {:.2e}; steps at 125 / 1 / 0 {}'.format(
         err, err_o, err_s, ['%.2e' % errs_i[i] for i in (125, 1, 0)]))
     kinds = [m_['variant'][0] for m_ in m._plan(64).meta if m_.get('variant') and m_.get('ksize') == 3]
-    print('3x3 launches by kernel family:', {k: kinds.count(k) for k in sorted(set(kinds))})
+    census = {k: kinds.count(k) for k in sorted(set(kinds))}
+    print('3x3 launches by kernel family:', census)
+    assert census == {'first': 1, 'wf4': 72}, census            # the committed plan: F(4x4) on 72 of 74 layers (the last is a 1x1 taps GEMM)
 
 
 @pytest.mark.parametrize('f4', ['tuned', 'everywhere', 'off'])

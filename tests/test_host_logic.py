@@ -232,6 +232,56 @@ def test_hand_scheduled_kernels_have_no_scratch_and_fit_two_waves_per_simd():
     assert seen == {'gemm4_kernel', 'gemm_bf16q_kernel', 'conv_wino4_kernel', 'conv_wf4_kernel'}, seen
 
 
+def _kernel_regs_tool():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kernel_regs', os.path.join(root, 'tools', 'kernel_regs.py'))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    return kr, os.path.join(root, 'nice-diffusion_amd', 'nicediffusion', 'libnd_hip.so')
+
+
+def test_hand_counted_waits_see_exactly_the_loads_they_count():
+    """conv_wf4_kernel and gemm4_kernel wait with LITERAL vmcnt / lgkmcnt values (wf4_younger, vmcnt(25 - NDMA - LDEARLY),
+    LPS + NDMA in gemm4's residual seeding) that assume the compiler puts no other memory operation into the main loop.  The
+    machine code of the built library is disassembled (tools/kernel_regs.py loop_table) and every loop that holds MFMAs must
+    contain exactly the operations the counts were written for: conv_wf4_kernel -- a loop body = two 16-channel chunks = 144
+    MFMAs, 48 fragment loads (global_load_dwordx3: 6 positions x 4 k4-steps x 2 chunks), 2 x NDMA halo DMAs (buffer_load ... lds:
+    NDMA = 2 for the 16x16-pixel geometry, 3 for the four-image one), two barriers and NOTHING else that counts on vmcnt or
+    lgkmcnt besides its ds_read_b64 (no other load, no store, no atomic, no scalar load, no LDS write); gemm4_kernel -- per
+    k-step 8 weight-fragment loads (16 with the GroupNorm coefficients), all global_load_dwordx4, pixel rows by LDS-DMA only.
+    A compiler or flag change that rematerialises an argument or reloads a descriptor inside these loops fails here instead
+    of reading registers before their data has landed."""
+    kr, so = _kernel_regs_tool()
+    wf4 = kr.loop_table(so, 'conv_wf4_kernel')
+    assert len(wf4) == 8, sorted(wf4)
+    for name, loops in wf4.items():
+        gw = int(re.search(r'conv_wf4_kernel<(\d+)', name).group(1))
+        main = [lp for lp in loops if any(k.startswith('v_mfma') for k in lp['counts'])]
+        assert len(main) == 2, (name, loops)                 # waves of transform rows 1-4 and of rows 0 / 5
+        for lp in main:
+            c = dict(lp['counts'])
+            assert c.pop('v_mfma_f32_16x16x4_f32') == 144, (name, lp)
+            assert c.pop('global_load_dwordx3') == 48, (name, lp)
+            assert c.pop('buffer_load_dwordx4_lds') == 2 * (2 if gw == 5 else 3), (name, lp)
+            assert c.pop('s_barrier') == 2, (name, lp)
+            assert c.pop('ds_read_b64') in (72, 96), (name, lp)
+            c.pop('s_waitcnt')
+            assert not c, (name, 'unexpected memory operations in the chunk loop', c)
+    g4 = kr.loop_table(so, 'gemm4_kernel')
+    assert len(g4) >= 6, sorted(g4)
+    for name, loops in g4.items():
+        gn = 'gemm4_kernel<true' in name
+        main = [lp for lp in loops if any(k.startswith('v_mfma') for k in lp['counts'])]
+        assert main, name
+        for lp in main:
+            c = dict(lp['counts'])
+            assert c.pop('global_load_dwordx4') == (16 if gn else 8), (name, lp)
+            for k in ('v_mfma_f32_32x32x2_f32', 'buffer_load_dwordx4_lds', 'ds_read_b128', 's_barrier', 's_waitcnt'):
+                assert c.pop(k, 0) > 0, (name, k, lp)
+            assert not c, (name, 'unexpected memory operations in the k loop', c)
+
+
 def test_conv_wf4_lds_halo_image_is_what_the_reads_expect():
     """conv_wf4_kernel fills its halo buffers by LDS-DMA (one 16-byte unit per lane and round, a 4-bit XOR key per 4-pixel group)
     and reads them back with per-lane addresses built from four keys: tools/wf4_lds_image.py restates both index maps and checks
@@ -258,12 +308,59 @@ def test_bench_weights_are_the_survey_recipe_the_parity_tests_use():
     assert list(got) == list(sd) and all(torch.equal(sd[k], v) for k, v in got.items())
 
 
+def test_shipped_library_is_the_product_build_of_the_sources_in_the_tree():
+    """nd_build_id() of the library in the tree is the SHA-256 the Makefile computes over the sources in the tree (a library
+    left over from an earlier state of csrc/ fails here), nd_build_flags() is empty (no timing-only / diagnostic macro was
+    defined for any translation unit), csrc/nd_variant_flags.inc lists every macro the sources test, and the stamp of every
+    measured artefact starts with the build id."""
+    from nicediffusion import _engine
+    lib = _hip.load()
+    assert lib.nd_build_flags() == b''
+    assert re.fullmatch(r'[0-9a-f]{16}', lib.nd_build_id().decode())
+    assert lib.nd_build_id().decode() == _hip.source_hash(), 'libnd_hip.so was not built from the sources in the tree: make -C nice-diffusion_amd'
+    assert _hip.build_id() == _hip.source_hash()
+    assert _engine._tune_stamp().startswith('b' + _hip.source_hash() + ':v')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_variant_flags', os.path.join(ROOT, 'tools', 'gen_variant_flags.py'))
+    gv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gv)
+    names = gv.scan()
+    assert len(names) >= 40 and 'ND_F4ABL_NOEPI' in names and 'ND_BF_DIAG' in names
+    assert open(gv.OUT).read() == gv.render(names), 'run python tools/gen_variant_flags.py'
+
+
+def test_an_ablation_build_is_refused_by_the_loader(monkeypatch):
+    """_hip.load() must not take a library that reports variant flags (simulated here on the loaded handle) unless
+    ND_ALLOW_ABLATION=1; with it, the flags become part of build_id() and therefore of every stamp."""
+    import ctypes
+    real = _hip.load()
+
+    class Fake:
+        def __getattr__(self, k):
+            return getattr(real, k)
+
+    fake = Fake()
+    fake.__dict__['nd_build_flags'] = lambda: b'ND_F4ABL_NOEPI=1 ND_F4_DIAG=1'
+    monkeypatch.setattr(_hip, '_LIB', None)
+    monkeypatch.setattr(ctypes, 'CDLL', lambda path: fake)
+    monkeypatch.delenv('ND_ALLOW_ABLATION', raising=False)
+    with pytest.raises(_hip.NdHipError, match='ND_F4ABL_NOEPI'):
+        _hip.load()
+    monkeypatch.setenv('ND_ALLOW_ABLATION', '1')
+    monkeypatch.setattr(_hip, '_LIB', None)
+    assert _hip.load() is fake
+    assert _hip.build_id() == _hip.source_hash() + '+ND_F4ABL_NOEPI=1,ND_F4_DIAG=1'
+    monkeypatch.setattr(_hip, '_LIB', real)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'nice-diffusion_amd',
                                                    'nicediffusion', 'libnd_hip.so')), reason='needs the built libnd_hip.so')
 def test_committed_tune_caches_match_the_built_library():
     """profiles/tune_cache_<workload>.json (the kernel choices bench.py and the full-size tests build their plans from) carry
-    the stamp of THIS library build -- version + variant tables -- so a kernel change that forgot to regenerate them is
-    flagged here instead of silently falling back to tuning on the box; every choice names an existing variant."""
+    the stamp of THIS library build -- the hash of its sources (nd_build_id), version, variant tables -- so a kernel change
+    that did not regenerate them (tools/tune_all.sh on an MI355X) is flagged here instead of silently falling back to tuning on
+    the box: editing one character of any .hip fails this test until the caches are regenerated.  Every choice names an
+    existing variant."""
     from nicediffusion import _engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = _hip.load()

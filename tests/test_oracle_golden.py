@@ -130,6 +130,48 @@ def test_sampler_trajectories(golden_dir, name):
     assert np.abs(out.numpy() - traj[-1]).max() < 1e-3
 
 
+@pytest.mark.parametrize('name', sorted(SAMPLER_CASES))
+def test_per_step_surface_pred_x0_clip_and_log_var(golden_dir, name):
+    """The (sample, pred_x0) tuples of the reference's public per-step methods (diffusion.py:266-369), clip_x=False,
+    get_eps_and_log_var and per-image step indices (tests/golden/sampler_steps_<case>.npz, tools/gen_golden.py
+    gen_sampler_steps): the oracle restates them (rows are independent, so a per-image index is one call per image)."""
+    g = _load(golden_dir, 'sampler_{}.npz'.format(name))
+    gs = _load(golden_dir, 'sampler_steps_{}.npz'.format(name))
+    case = SAMPLER_CASES[name]
+    cfg = dict(TINY_CFGS[case['cfg']])
+    learned = case['var'] in ('learned', 'learned_interpolation')
+    cfg['out_channels'] = cfg['in_channels'] * (2 if learned else 1)
+    sd = UO.synth_state_dict(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+    S = case['S']
+    so = DO.SamplerOracle(lambda xx, tt, yy: UO.unet_forward(sd, cfg, xx, tt, yy), DO.Schedule(1000, S, case['sched']), case['var'],
+                          use_ddim=case['ddim'], ddim_eta=case.get('eta'), guidance_method=case.get('guidance'),
+                          guidance_strength=case.get('w'))
+    y = torch.from_numpy(g['y']) if 'y' in g.files else None
+    noises, traj, xT = torch.from_numpy(g['noises']), torch.from_numpy(g['traj']), torch.from_numpy(g['xT'])
+    step = so.ddim_step if case['ddim'] else so.ddpm_step
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    # pred_x0 = c_t x - c'_t eps (diffusion.py:287-288) with c'_t up to 404 at the head of a 10-step chain: a 1e-7 difference in
+    # eps (the CPU convolutions of a batch of 1 and of 2 differ by that) is 4e-5 in pred_x0 -- the bound scales with c'_t
+    ptol = lambda t: 1e-5 + 5e-7 * float(so.s.sqrt_reciprocal_alphas_minus_one_cumprod[t])
+    for i, t in enumerate(reversed(range(S))):
+        xt = xT if i == 0 else traj[i - 1]
+        _, p0 = step(xt, t, y, noises[t])
+        assert np.abs(p0.numpy() - gs['pred_x0'][i]).max() < ptol(t), (name, t)
+        a, b = step(xt, t, y, noises[t], clip_x=False)
+        assert rel(a.numpy(), gs['noclip_sample'][i]) < 1e-5 and rel(b.numpy(), gs['noclip_pred_x0'][i]) < 1e-5, (name, t)
+    xm = torch.from_numpy(gs['mixed_x'])
+    for b, t in enumerate(int(v) for v in gs['t_mixed']):
+        yy = None if y is None else y[b:b + 1]
+        smp, p0 = step(xm[b:b + 1], t, yy, noises[0][b:b + 1])
+        assert rel(smp.numpy(), gs['mixed_sample'][b:b + 1]) < 1e-5
+        assert np.abs(p0.numpy() - gs['mixed_pred_x0'][b:b + 1]).max() < ptol(t), (name, t)
+        q = so.diffuse(torch.tanh(xT[b:b + 1]), t + 1, noises[1][b:b + 1])
+        assert rel(q.numpy(), gs['q_mixed'][b:b + 1]) < 1e-6
+    for k, t in enumerate(int(v) for v in gs['eps_indices']):
+        e, lv = so.eps_and_log_var(xm, t, y)
+        assert rel(e.numpy(), gs['eps'][k]) < 1e-5 and rel(lv.numpy(), gs['log_var'][k]) < 1e-5, (name, t)
+
+
 def test_config1_end_to_end(golden_dir):
     """BASELINE configs[0]: EMNIST preset, 50-step DDIM, B=4 on the CPU."""
     g = _load(golden_dir, 'config1_emnist_ddim50.npz')

@@ -241,6 +241,73 @@ def gen_samplers():
         save('sampler_{}.npz'.format(name), **arrs)
 
 
+# ------------------------------------------------------------------------------------------------ public per-step surface
+def gen_sampler_steps():
+    """The reference's public per-step methods (diffusion.py:232-369) as a caller that walks the chain itself sees them:
+    for every sampler case, teacher-forced along the stored trajectory of sampler_<case>.npz (x_t of step i = x_T or the
+    reference's own x after step i - 1, the stored noise draws): the (sample, pred_x0) tuple of ddim_denoising_step /
+    denoising_step with clip_x=True (sample must equal the stored trajectory) and with clip_x=False, get_eps_and_log_var at
+    three step indices, one step with a DIFFERENT step index per image (t = [S - 1, 0]) and diffusion_step with per-image
+    indices."""
+    for name, case in SAMPLER_CASES.items():
+        g = np.load(os.path.join(OUT, 'sampler_{}.npz'.format(name)))
+        cfg = dict(TINY_CFGS[case['cfg']])
+        learned = case['var'] in ('learned', 'learned_interpolation')
+        cfg['out_channels'] = cfg['in_channels'] * (2 if learned else 1)
+        sd = UO.synth_state_dict(cfg, seed=case.get('wseed', 99), sigma_zero=case.get('sigma_zero', 0.005))
+        m = ref_model(cfg, sd)
+        S = case['S']
+        d = Diffusion(m, 1000, S, case['var'], 'simple', beta_schedule=case['sched'],
+                      guidance_method=case.get('guidance'), guidance_strength=case.get('w'),
+                      use_ddim=case['ddim'], ddim_eta=case.get('eta'), device=torch.device('cpu'))
+        xT, noises, traj = torch.from_numpy(g['xT']), torch.from_numpy(g['noises']), torch.from_numpy(g['traj'])
+        B = xT.shape[0]
+        kwargs = {'y': torch.from_numpy(g['y'])} if 'y' in g.files else {}
+        step = d.ddim_denoising_step if case['ddim'] else d.denoising_step
+        cur = {}
+        orig = torch.randn_like
+
+        def fake_randn_like(z, *a, **k):
+            return cur['n'].clone()
+        torch.randn_like = fake_randn_like
+        try:
+            pred, s_nc, p_nc = [], [], []
+            for i, t in enumerate(reversed(range(S))):
+                xt = xT if i == 0 else traj[i - 1]
+                ts = t * torch.ones(B)
+                cur['n'] = noises[t]
+                with torch.no_grad():
+                    smp, p0 = step(xt, ts, kwargs)
+                    assert torch.equal(smp, traj[i]), (name, t)
+                    pred.append(p0.float())
+                    a, b = step(xt, ts, kwargs, clip_x=False)
+                    s_nc.append(a.float())
+                    p_nc.append(b.float())
+            # one step index per image: image 0 at the head of the chain, image 1 at its masked last step
+            t_mixed = torch.tensor([float(S - 1), 0.0])
+            cur['n'] = noises[0]
+            with torch.no_grad():
+                mix_s, mix_p = step(traj[S // 2], t_mixed, kwargs)
+                eidx = [S - 1, S // 2, 0]
+                eps, lv = [], []
+                for t in eidx:
+                    e, v = d.get_eps_and_log_var(traj[S // 2], t * torch.ones(B), kwargs)
+                    eps.append(e.float())
+                    lv.append(v.expand(e.shape).float())
+            x0 = torch.tanh(xT)
+            q = d.diffusion_step(x0, t_mixed, noise=noises[1])
+        finally:
+            torch.randn_like = orig
+        clipped = float((torch.stack(p_nc).abs() > 1).float().mean())
+        print('  ', name, 'fraction of pred_x0 elements the clamp acts on', round(clipped, 3), 'noclip absmax',
+              float(torch.stack(p_nc).abs().max()))
+        assert clipped > 0.01, 'clip_x=False case does not differ from the clipped one'
+        save('sampler_steps_{}.npz'.format(name), pred_x0=torch.stack(pred).numpy(), noclip_sample=torch.stack(s_nc).numpy(),
+             noclip_pred_x0=torch.stack(p_nc).numpy(), t_mixed=t_mixed.numpy(), mixed_x=traj[S // 2].numpy(),
+             mixed_sample=mix_s.float().numpy(), mixed_pred_x0=mix_p.float().numpy(), eps_indices=np.array(eidx),
+             eps=torch.stack(eps).numpy(), log_var=torch.stack(lv).numpy(), q_mixed=q.float().numpy())
+
+
 # ------------------------------------------------------------------------------------------------ config 1 end-to-end
 def gen_config1():
     """BASELINE config[0]: EMNIST preset model, 50-step DDIM eta=0, B=4, CPU (SURVEY 8(d) Config 1)."""
@@ -457,8 +524,8 @@ def gen_embed():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'cli', 'config1', 'presets', 'diffuse', 'config2', 'config2_steps', 'large_rows']
-    fns = dict(config2_steps=gen_config2_steps, diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
+    which = sys.argv[1:] or ['schedules', 'embed', 'tiny', 'init', 'samplers', 'sampler_steps', 'cli', 'config1', 'presets', 'diffuse', 'config2', 'config2_steps', 'large_rows']
+    fns = dict(sampler_steps=gen_sampler_steps, config2_steps=gen_config2_steps, diffuse=gen_diffuse, schedules=gen_schedules, embed=gen_embed, tiny=gen_tiny_forwards, init=gen_init,
                samplers=gen_samplers, cli=gen_cli, config1=gen_config1, presets=gen_presets, config2=gen_config2,
                large_rows=gen_large_rows)
     for w in which:

@@ -72,11 +72,11 @@ d = Diffusion(m, 1000, 250, 'learned_interpolation', 'hybrid', beta_schedule='co
 coef = d.coefficient_table().to(dev)
 step = torch.full((1,), 100, dtype=torch.int32, device=dev)
 report('nd_ddim_step (K10, eta=0)', NI * HW * (CP * 4 * 2 + 8 * 4),
-       timed(lambda: ck(lib.nd_ddim_step(x_nhwc.data_ptr(), out.data_ptr(), None, CP, eps.data_ptr(), None, 8, 0.0,
+       timed(lambda: ck(lib.nd_ddim_step(x_nhwc.data_ptr(), out.data_ptr(), None, None, 0, CP, eps.data_ptr(), None, 8, 0.0,
                                          coef.data_ptr(), step.data_ptr(), 0.0, None, 0, 0, None, 0, NI, HW, C, st))),
        'read x (NHWC4) + model output (NHWC8), write x')
 report('nd_ddpm_step (K10, learned_interpolation, Philox noise)', NI * HW * (CP * 4 * 2 + 8 * 4),
-       timed(lambda: ck(lib.nd_ddpm_step(x_nhwc.data_ptr(), out.data_ptr(), None, CP, eps.data_ptr(), None, 8, 0.0,
+       timed(lambda: ck(lib.nd_ddpm_step(x_nhwc.data_ptr(), out.data_ptr(), None, None, 0, CP, eps.data_ptr(), None, 8, 0.0,
                                          coef.data_ptr(), step.data_ptr(), 2, None, 0, 1234, None, 0, NI, HW, C, st))),
        'same traffic; noise generated in-kernel')
 

@@ -1,6 +1,11 @@
+# Regenerate the committed kernel choices after ANY change under csrc/ (their stamp carries nd_build_id, the hash of the
+# sources): run on the GPU box, then copy gpurun_out/tune_cache_<workload>.json over profiles/tune_cache_<workload>.json.
+# Short chains: the choices depend on the layer shapes only.
 set -u
 mkdir -p gpurun_out
 for WL in config2 config4 config5 config1; do
-  python bench.py --workload $WL --steps 2 --warmup 1 --retune --save-tune-cache gpurun_out/tune_cache_$WL.json > gpurun_out/r05_pre_bench_$WL.json 2> gpurun_out/r05_pre_bench_$WL.err || echo "bench $WL failed"
-  tail -1 gpurun_out/r05_pre_bench_$WL.err
+  python3 bench.py --workload $WL --steps 1 --warmup 1 --chain 10 --no-cpu-baseline --no-breakdown --retune \
+      --save-tune-cache gpurun_out/tune_cache_$WL.json > gpurun_out/tune_bench_$WL.json 2> gpurun_out/tune_bench_$WL.err || echo "tune $WL failed"
+  tail -1 gpurun_out/tune_bench_$WL.err
+  echo "tuned $WL"
 done
