@@ -256,16 +256,22 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     auto advance_b = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-#if !defined(ND_HABL_NOB)        // timing-only ablation: weight fragments stay whatever the registers hold
+#if defined(ND_HABL_BL1)          // timing-only ablation: every wave of the chip loads the SAME 2 KiB every k-step (hits in its CU's L1)
+            dst[ni] = *reinterpret_cast<const f32x4*>(p.w + (size_t)ni * 512 + lane * 8);
+#elif !defined(ND_HABL_NOB)      // timing-only ablation: weight fragments stay whatever the registers hold
             dst[ni] = *reinterpret_cast<const f32x4*>(bp[ni]);
 #endif
+#if !defined(ND_HABL_BHIT)       // timing-only ablation (BHIT): a wave re-reads its first fragments every k-step (its own L1 / L2 lines)
             bp[ni] += K16 ? 4 * 512 : 512;          // K16: the tap's k-steps 1..3 are skipped
+#endif
         }
+#if !defined(ND_HABL_BHIT)
         if (++ld_in_c64 == (K16 ? TAPS : STEPS)) {
             ld_in_c64 = 0;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) bp[ni] += c64_jump;
         }
+#endif
     };
     // one k-step: TM x TN MFMAs; behind tile mi's MFMAs its fragment for the next step is read from LDS word offset
     // noff[mi] (already swizzled)

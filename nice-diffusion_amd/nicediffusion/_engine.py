@@ -32,7 +32,7 @@ def _tune_cache_path():
     return os.environ.get('ND_TUNE_CACHE')
 
 
-def _tune_stamp():
+def _tune_stamp(product=False):
     """What a file of measured choices (or any other measured artefact) is only valid for: the library's SOURCE HASH
     (nd_build_id: one changed character of any kernel source changes it -- nobody has to remember to bump a version),
     its variant flags if it is an ablation build, its version and its variant tables (a choice is a variant NUMBER)."""
@@ -46,7 +46,9 @@ def _tune_stamp():
     for v in range(lib.nd_conv_num_variants()):
         lib.nd_conv_variant_info(v, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nt))
         direct.append('{}x{}x{}'.format(bm.value, bn.value, nt.value))
-    return 'b{}:v{}:d{}:{}:{}'.format(_hip.build_id(), lib.nd_version(), lib.nd_conv_num_variants(), ','.join(direct), '|'.join(names))
+    # product=True: the stamp the PRODUCT build of the same sources carries (the variant flags of an ablation build dropped)
+    bid = _hip.build_id().split('+')[0] if product else _hip.build_id()
+    return 'b{}:v{}:d{}:{}:{}'.format(bid, lib.nd_version(), lib.nd_conv_num_variants(), ','.join(direct), '|'.join(names))
 
 
 def preload_tune_cache(path, device_index=None, override=False):
@@ -58,9 +60,19 @@ def preload_tune_cache(path, device_index=None, override=False):
         raw = json.load(open(path))
     except (ValueError, OSError):
         return 0
-    if raw.pop('__stamp__', None) != _tune_stamp():
-        print('[nd] tune cache {} was written by another library build: ignored'.format(path), file=sys.stderr)
-        return 0
+    stamp = raw.pop('__stamp__', None)
+    if stamp != _tune_stamp():
+        # an ablation / experiment build (loaded under ND_ALLOW_ABLATION=1) is timed on the PRODUCT's plan: it takes the cache
+        # of the product build of the same sources; files it writes itself carry its own flagged stamp
+        # (ND_TUNE_STAMP_ANY=1, development only: A/B runs between the edit of a kernel and the regeneration of the caches; the
+        # switch shows in the bench line's config.switches)
+        if os.environ.get('ND_TUNE_STAMP_ANY') == '1':
+            print('[nd] ND_TUNE_STAMP_ANY=1: taking {} although it was written by another library build'.format(path), file=sys.stderr)
+        elif not ('+' in _hip.build_id() and stamp == _tune_stamp(product=True)):
+            print('[nd] tune cache {} was written by another library build: ignored'.format(path), file=sys.stderr)
+            return 0
+        else:
+            print('[nd] variant build {}: taking the product build\'s tune cache {}'.format(_hip.build_id(), path), file=sys.stderr)
     if device_index is None:
         device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
     n = 0
@@ -887,9 +899,18 @@ class UNetPlan:
         if ksize == 3 and H % 2 == 0 and W % 2 == 0 and os.environ.get('ND_WINOGRAD', '1') != '0':
             wq = self._packed_wino(weight, pad_c_to)
             for v in range(self.lib.nd_conv_winograd_num_variants()):      # (retired variant numbers refuse the launch)
-                ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
-                if ms is not None and self.lib.nd_conv_winograd_variant_name(v) != b'nd::conv_wino4_kernel':
-                    ms += pass_ms
+                # every candidate is priced as the plan would run it: a kernel that can leave the output's statistics behind
+                # (conv_wino4_kernel) is timed WITH that epilogue when they are wanted (it used to be timed without,
+                # i.e. under-priced against the F(4x4) and 1x1 candidates, which are timed with theirs); the others pay the pass
+                rows_v = self.lib.nd_conv_winograd_stats_rows(v, NI, H, W) if (stats_wanted and pass_ms > 0 and not gn[0]) else 0
+                if rows_v > 0 and self.lib.nd_conv_winograd_variant_name(v) == b'nd::conv_wino4_kernel':
+                    sbuf_v = torch.empty(NI * rows_v * 2 * N, dtype=torch.float32, device=self.device)
+                    ms = time_it(self.lib.nd_conv3x3_winograd_vstats_nhwc, head + [wq.data_ptr()] + tail + [flags, v, sbuf_v.data_ptr()])
+                    del sbuf_v
+                else:
+                    ms = time_it(self.lib.nd_conv3x3_winograd_nhwc, head + [wq.data_ptr()] + tail + [flags, v] + gn)
+                    if ms is not None and self.lib.nd_conv_winograd_variant_name(v) != b'nd::conv_wino4_kernel':
+                        ms += pass_ms
                 if ms is not None and (best_ms is None or ms < best_ms):
                     best, best_ms = ('wino', v), ms
             if splitk_ok:

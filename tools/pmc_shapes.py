@@ -26,7 +26,7 @@ CONV_KERNELS = ('conv_wino16_kernel', 'conv_wino_kernel', 'conv_wino4_kernel', '
 # the other kernel classes of a forward: counters aggregated per kernel name (no per-shape key)
 CLASS_KERNELS = ('attention_kernel', 'attention_bf16_kernel', 'gn_stats_kernel', 'gn_apply_kernel', 'gn_from_partials_kernel',
                  'gn_coeffs_kernel', 'gn_coeffs_from_partials_kernel', 'gn_fused_small_kernel', 'splitk_reduce_kernel', 'splitk_reduce_f32_kernel')
-OUT_NAME = os.environ.get('ND_PMC_OUT', os.environ.get('ROUND', 'r05') + '_pmc_shapes.json')
+OUT_NAME = os.environ.get('ND_PMC_OUT', os.environ.get('ROUND', 'r06') + '_pmc_shapes.json')
 
 
 def dispatches(d, kernels=CONV_KERNELS):

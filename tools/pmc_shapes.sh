@@ -1,4 +1,4 @@
-# Regenerates profiles/${ROUND:-r05}_pmc_shapes.json (ND_PMC_OUT names another file): per-shape HBM traffic + matrix-pipe counters of every conv launch inside a
+# Regenerates profiles/${ROUND:-r06}_pmc_shapes.json (ND_PMC_OUT names another file): per-shape HBM traffic + matrix-pipe counters of every conv launch inside a
 # forward.  Run on the GPU box from the repo root:   bash tools/pmc_shapes.sh [config2|config4|config5]
 # (separate --pmc passes with --kernel-trace only, the python program directly after `--`).
 WL=${1:-config2}

@@ -1,10 +1,10 @@
-# Round profile set (run on the GPU box from the repo root; ROUND=r05 by default):
+# Round profile set (run on the GPU box from the repo root; ROUND=r06 by default):
 #   1. bench lines of the four workloads (the committed tune caches profiles/tune_cache_<workload>.json are loaded by bench.py);
 #   2. rocprofv3 --kernel-trace --stats summaries of bench.py for config2 / config4 / config5 (eager launches, short chains);
 #   3. per-shape PMC tables (conv launches keyed by shape + the attention / GroupNorm classes) for config2 / config4 / config5.
 # Everything lands in gpurun_out/${ROUND}_* (the box only returns gpurun_out/); copy what is to be judged into profiles/.
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 export ROUND
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
