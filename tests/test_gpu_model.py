@@ -204,7 +204,7 @@ def test_public_per_step_methods_vs_reference_golden(golden_dir, name):
     step = d.ddim_denoising_step if case['ddim'] else d.denoising_step
     rel = lambda a, b: float(np.abs(a.cpu().numpy() - b).max() / max(1.0, np.abs(b).max()))
     cm1 = d.sqrt_reciprocal_alphas_minus_one_cumprod
-    ptol = lambda t: 2e-5 + 4e-6 * float(cm1[t])            # eps within 4e-6 of the reference's
+    ptol = lambda t: 6e-6 + 1.2e-6 * float(cm1[t])          # measured <= 0.12 of (2e-5 + 4e-6 c_t) on MI355X: eps within 1.2e-6
     worst = dict(sample=0.0, pred=0.0, noclip=0.0)
     for i, t in enumerate(reversed(range(S))):
         xt = xT if i == 0 else torch.from_numpy(traj[i - 1])
