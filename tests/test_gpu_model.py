@@ -767,11 +767,20 @@ def test_full_size_config2_plan_vs_reference_rows_and_oracle(golden_dir):
         st_i = d.denoise(x=xt, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=1, first_index=i, progress=False)
         errs_i[i] = float(np.abs(st_i[rows].cpu().numpy() - gs['step_%d' % i]).max())
         assert errs_i[i] < 1e-4, errs_i                         # measured 1e-5 ... 2e-5 with Winograd F(4x4,3x3) on every 3x3 layer
+        # the same step through the reference's PUBLIC method on the B = 64 plan (round 6): float32 [B] indices as diffusion.py:216
+        # builds them -> (sample, pred_x0); the sample is the loop's own bit for bit, pred_x0 = c_t x - c'_t eps is held to the eps
+        # bound of the forward (1e-4 / absmax-0.63 output) scaled by c'_t (1.9 at index 125, 0.04 at index 1)
+        smp_i, pred_i = d.ddim_denoising_step(xt.to(DEV), (i * torch.ones(64)).to(DEV), {'y': y.to(DEV)})
+        assert torch.equal(smp_i, st_i), i
+        e_p = float(np.abs(pred_i[rows].cpu().numpy() - gs['pred_x0_%d' % i]).max())
+        assert e_p < 2e-5 + 1e-4 * float(d.sqrt_reciprocal_alphas_minus_one_cumprod[i]), (i, e_p)
+        errs_i[('pred_x0', i)] = e_p
     a = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     b = d.denoise(x=x, kwargs={'y': y.to(DEV)}, batch_size=64, steps_to_do=3, progress=False)
     assert torch.isfinite(a).all() and torch.equal(a, b)
     print('config2 B=64 plan: forward rows vs reference {:.2e}, vs oracle {:.2e}; DDIM step vs reference {:.2e}; steps at 125 / 1 / 0 {}'.format(
-        err, err_o, err_s, ['%.2e' % errs_i[i] for i in (125, 1, 0)]))
+        err, err_o, err_s, ['%.2e' % errs_i[i] for i in (125, 1, 0)]),
+        '; pred_x0 of the public ddim_denoising_step at those indices', ['%.2e' % errs_i[('pred_x0', i)] for i in (125, 1, 0)])
     kinds = [m_['variant'][0] for m_ in m._plan(64).meta if m_.get('variant') and m_.get('ksize') == 3]
     census = {k: kinds.count(k) for k in sorted(set(kinds))}
     print('3x3 launches by kernel family:', census)

@@ -417,12 +417,13 @@ def gen_config2_steps():
     for i in (125, 1, 0):
         xt = d.diffuse(x0, steps_to_do=i + 1, noise=nz)
         with torch.no_grad():
-            step, _ = d.ddim_denoising_step(xt, i * torch.ones(len(idx)), {'y': yr})
+            step, pred = d.ddim_denoising_step(xt, i * torch.ones(len(idx)), {'y': yr})
         e = (so.ddim_step(xt, i, yr)[0] - step).abs().max().item()
         print('   config2 rows DDIM step at index', i, 'oracle-vs-reference', e, 'absmax', step.abs().max().item())
         assert e < 5e-5
         arrs['xt_%d' % i] = xt.numpy()
         arrs['step_%d' % i] = step.numpy()
+        arrs['pred_x0_%d' % i] = pred.float().numpy()          # round 6: the second element of the reference's tuple
     save('config2_headline_steps.npz', **arrs)
 
 
