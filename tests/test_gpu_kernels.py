@@ -698,6 +698,109 @@ def test_sampler_generic_form_matches_image_form(ddim):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('ddim', [True, False])
+@pytest.mark.parametrize('ldx,lde', [(4, 8), (8, 12)])
+def test_sampler_extended_form_pred_x0_noclip_per_image(ddim, ldx, lde):
+    """The extended forms behind the public per-step methods (round 6) -- pred_x0 output, ND_STEP_NO_CLIP, ND_STEP_PER_IMAGE --
+    in BOTH kernels (per-pixel 16-byte form: ldx 4 / ld_eps 8; per-element form: any strides) against an fp32 PyTorch statement
+    of diffusion.py:287-313 / :350-366 with one step index per image (the last image takes the masked t = 0 step).  With the
+    flags off and no pred_x0 the launch runs the loop's own form: same sample bits as the extended launch with the clamp on."""
+    B, C, HW, S = 3, 3, 50, 6
+    x, eps = rnd(B, HW, C, seed=1, scale=2.0), rnd(B, HW, 2 * C, seed=2, scale=0.5)
+    nz = rnd(B, HW, C, seed=3)
+    coef = (torch.rand(S, 8, generator=torch.Generator().manual_seed(5)) * 0.5 + 0.4)
+    coef[:, 3] = coef[:, 2] + 0.05                                     # abar_prev > abar
+    coef[:, 6:] = -coef[:, 6:]                                         # log-variances
+    steps = torch.tensor([4, 2, 0], dtype=torch.int32)
+    eta = 0.6
+    xd = torch.zeros(B, HW, ldx); xd[..., :C] = x
+    ed = torch.zeros(B, HW, lde); ed[..., :2 * C] = eps
+    nd_ = torch.zeros(B, HW, ldx); nd_[..., :C] = nz
+    xd, ed, nd_, cd, sd = xd.to(DEV), ed.to(DEV), nd_.to(DEV), coef.to(DEV), steps.to(DEV)
+
+    def ref(clip):
+        cf = coef[steps.long()][:, None, :]                            # [B, 1, 8]
+        e, lv = eps[..., :C], eps[..., C:]
+        x0 = cf[..., 0:1] * x - cf[..., 1:2] * e
+        if clip:
+            x0 = x0.clamp(-1, 1)
+        mask = (steps != 0).float()[:, None, None]
+        if ddim:
+            ab, abp = cf[..., 2:3], cf[..., 3:4]
+            var = eta ** 2 * (1.0 - abp) * (1.0 - ab / abp) / (1.0 - ab)
+            out = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - var) * e + mask * torch.sqrt(var) * nz
+        else:
+            frac = (lv + 1) / 2
+            log_var = frac * cf[..., 7:8] + (1 - frac) * cf[..., 6:7]
+            out = cf[..., 4:5] * x0 + cf[..., 5:6] * x + mask * torch.exp(0.5 * log_var) * nz
+        return out, x0
+
+    def launch(pred, flags, step_t):
+        out = torch.zeros_like(xd)
+        args = (xd.data_ptr(), out.data_ptr(), None, None if pred is None else pred.data_ptr(), flags, ldx, ed.data_ptr(), None, lde, 0.0,
+                cd.data_ptr(), step_t.data_ptr())
+        tail = (nd_.data_ptr(), 0, 0, None, 0, B, HW, C, st())
+        rc = lib().nd_ddim_step(*args, eta, *tail) if ddim else lib().nd_ddpm_step(*args, _hip.VAR_LEARNED_INTERP, *tail)
+        _hip.check(rc)
+        return out
+
+    for clip in (True, False):
+        pred = torch.full_like(xd, 7.0)
+        out = launch(pred, _hip.STEP_PER_IMAGE | (0 if clip else _hip.STEP_NO_CLIP), sd)
+        r_out, r_x0 = ref(clip)
+        scale = max(1.0, r_x0.abs().max().item())
+        assert (out[..., :C].cpu() - r_out).abs().max().item() < 2e-6 * scale, clip
+        assert (pred[..., :C].cpu() - r_x0).abs().max().item() < 2e-6 * scale, clip
+    assert ref(False)[1].abs().max().item() > 1.5                      # the clamp matters on this data
+    # uniform step word, clamp on: the extended launch (pred_x0 requested) and the loop's own launch give the same sample bits
+    one = torch.tensor([2], dtype=torch.int32, device=DEV)
+    pred = torch.zeros_like(xd)
+    assert torch.equal(launch(pred, 0, one), launch(None, 0, one))
+    # pred_x0 must be its own buffer; unknown flags are refused
+    out = torch.zeros_like(xd)
+    bad = (xd.data_ptr(), out.data_ptr(), None, out.data_ptr(), 0, ldx, ed.data_ptr(), None, lde, 0.0, cd.data_ptr(), one.data_ptr())
+    tail = (None, 0, 0, None, 0, B, HW, C, st())
+    assert (lib().nd_ddim_step(*bad, eta, *tail) if ddim else lib().nd_ddpm_step(*bad, _hip.VAR_FIXED, *tail)) != 0
+    bad = bad[:3] + (None, 64) + bad[5:]
+    assert (lib().nd_ddim_step(*bad, eta, *tail) if ddim else lib().nd_ddpm_step(*bad, _hip.VAR_FIXED, *tail)) != 0
+
+
+@pytest.mark.parametrize('var_kind', [_hip.VAR_FIXED, _hip.VAR_LEARNED, _hip.VAR_LEARNED_INTERP])
+def test_eps_log_var_and_qsample_steps(var_kind):
+    """nd_eps_log_var (Diffusion.get_eps_and_log_var after the model call, diffusion.py:248-264: NHWC model output -> eps and
+    log-variance, both NCHW, one step index per image) and nd_qsample_steps (diffusion_step with per-image indices,
+    diffusion.py:232-240) against PyTorch statements."""
+    B, C, HW, S, ld = 3, 3, 37, 5, 8
+    o = rnd(B, HW, ld, seed=1)
+    coef = rnd(S, 8, seed=2)
+    steps = torch.tensor([4, 0, 2], dtype=torch.int32)
+    od, cd, sd = o.to(DEV), coef.to(DEV), steps.to(DEV)
+    eps = torch.full((B, C, HW), 9.0, device=DEV)
+    lv = torch.full((B, C, HW), 9.0, device=DEV)
+    _hip.check(lib().nd_eps_log_var(od.data_ptr(), ld, cd.data_ptr(), sd.data_ptr(), var_kind, eps.data_ptr(), lv.data_ptr(), B, HW, C, st()))
+    assert torch.equal(eps.cpu(), o[..., :C].permute(0, 2, 1))
+    cf = coef[steps.long()]
+    raw = o[..., C:2 * C].permute(0, 2, 1)
+    if var_kind == _hip.VAR_LEARNED:
+        want = raw
+    elif var_kind == _hip.VAR_LEARNED_INTERP:
+        frac = (raw + 1) / 2
+        want = frac * cf[:, 7][:, None, None] + (1 - frac) * cf[:, 6][:, None, None]
+    else:
+        want = cf[:, 6][:, None, None].expand(B, C, HW)
+    assert (lv.cpu() - want).abs().max().item() < 1e-6
+    assert lib().nd_eps_log_var(od.data_ptr(), C, cd.data_ptr(), sd.data_ptr(), _hip.VAR_LEARNED, eps.data_ptr(), lv.data_ptr(), B, HW, C, st()) != 0
+    if var_kind == _hip.VAR_FIXED:
+        x0, nz = rnd(B, C, 5, 7, seed=3).to(DEV), rnd(B, C, 5, 7, seed=4).to(DEV)
+        sa, sb = torch.rand(S, generator=torch.Generator().manual_seed(6)), torch.rand(S, generator=torch.Generator().manual_seed(7))
+        out = torch.empty_like(x0)
+        _hip.check(lib().nd_qsample_steps(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), B, C * 35, sa.to(DEV).data_ptr(), sb.to(DEV).data_ptr(),
+                                          sd.data_ptr(), st()))
+        want = sa[steps.long()][:, None, None, None] * x0.cpu() + sb[steps.long()][:, None, None, None] * nz.cpu()
+        assert (out.cpu() - want).abs().max().item() < 1e-6
+        assert lib().nd_qsample_steps(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), 0, C * 35, None, None, sd.data_ptr(), st()) != 0
+
+
 @pytest.mark.parametrize('NI,HW,C', [(3, 64, 3), (2, 49, 3), (5, 16, 1), (1, 7, 1)])
 def test_to_uint8_forms(NI, HW, C):
     """4-pixels-per-thread form (pixel count % 4 == 0) and the per-element form, with and without inversion."""

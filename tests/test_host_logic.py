@@ -90,6 +90,19 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 1, 8, 8), torch.zeros(1, dtype=torch.long), y=torch.zeros(1, dtype=torch.long))
     with pytest.raises(AssertionError):
         m(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))
+    # the public per-step methods (diffusion.py:232-369) have no CPU path either
+    t = torch.zeros(1)
+    for call in (lambda: d.ddim_denoising_step(torch.zeros(1, 1, 8, 8), t), lambda: d.denoising_step(torch.zeros(1, 1, 8, 8), t),
+                 lambda: d.get_eps_and_log_var(torch.zeros(1, 1, 8, 8), t, {}), lambda: d.diffusion_step(torch.zeros(1, 1, 8, 8), t)):
+        with pytest.raises(_hip.NdHipError):
+            call()
+    # ... and the reference's surface is all there, with its signatures (diffusion.py:232,242,266,318)
+    import inspect
+    for name, params in (('diffusion_step', ['x_0', 't', 'noise']), ('get_eps_and_log_var', ['x_t', 't', 'kwargs']),
+                         ('denoising_step', ['x_t', 't', 'kwargs', 'clip_x']), ('ddim_denoising_step', ['x_t', 't', 'kwargs', 'clip_x'])):
+        got = list(inspect.signature(getattr(Diffusion, name)).parameters)[1:]
+        assert got[:len(params)] == params, (name, got)
+    assert inspect.signature(Diffusion.denoising_step).parameters['clip_x'].default is True
 
 
 def test_product_never_imports_oracle():
