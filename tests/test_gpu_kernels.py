@@ -794,7 +794,8 @@ def test_eps_log_var_and_qsample_steps(var_kind):
         x0, nz = rnd(B, C, 5, 7, seed=3).to(DEV), rnd(B, C, 5, 7, seed=4).to(DEV)
         sa, sb = torch.rand(S, generator=torch.Generator().manual_seed(6)), torch.rand(S, generator=torch.Generator().manual_seed(7))
         out = torch.empty_like(x0)
-        _hip.check(lib().nd_qsample_steps(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), B, C * 35, sa.to(DEV).data_ptr(), sb.to(DEV).data_ptr(),
+        sad, sbd = sa.to(DEV), sb.to(DEV)          # (named: a temporary's storage would be recycled before the launch reads it)
+        _hip.check(lib().nd_qsample_steps(x0.data_ptr(), nz.data_ptr(), out.data_ptr(), B, C * 35, sad.data_ptr(), sbd.data_ptr(),
                                           sd.data_ptr(), st()))
         want = sa[steps.long()][:, None, None, None] * x0.cpu() + sb[steps.long()][:, None, None, None] * nz.cpu()
         assert (out.cpu() - want).abs().max().item() < 1e-6
