@@ -832,6 +832,10 @@ def test_full_batch_fp32_forward_rows_vs_reference(golden_dir, name, pname, B, c
     margs = dict(getattr(DA, pname + '_MODEL_ARGS'))
     if cfg:
         margs['num_classes'] += 1
+    # the kernel choices of this fp32 plan are committed too (profiles/tune_cache_<workload>_fp32.json, written by this very test
+    # under ND_TUNE_CACHE on an MI355X; asserted to be taken in full): every box checks the same plan, without ~50 s of tuning
+    if not os.environ.get('ND_TUNE_CACHE'):          # (set = regeneration mode, tools/tune_all.sh: the plan is tuned here and saved)
+        _preload_committed_tune_cache(name + '_fp32')
     m = build(margs)
     out = full_batch_forward(m, margs['resolution'], B, cfg, int(g['t'][0]))
     rows, st = torch.from_numpy(g['rows']), int(g['stride'])

@@ -377,7 +377,7 @@ def test_committed_tune_caches_match_the_built_library():
     from nicediffusion import _engine
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = _hip.load()
-    for wl in ('config1', 'config2', 'config4', 'config5'):
+    for wl in ('config1', 'config2', 'config4', 'config5', 'config4_fp32', 'config5_fp32'):
         path = os.path.join(root, 'profiles', 'tune_cache_{}.json'.format(wl))
         raw = json.load(open(path))
         assert raw.pop('__stamp__') == _engine._tune_stamp(), wl

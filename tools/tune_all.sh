@@ -9,3 +9,11 @@ for WL in config2 config4 config5 config1; do
   tail -1 gpurun_out/tune_bench_$WL.err
   echo "tuned $WL"
 done
+# the fp32 plans of configs[3] / [4] at their full forward batch (tests/test_gpu_model.py::test_full_batch_fp32_forward_rows_vs_reference
+# checks them against the reference's rows): the test itself writes the cache under ND_TUNE_CACHE
+for WL in config4 config5; do
+  rm -f gpurun_out/tune_cache_${WL}_fp32.json
+  ND_TUNE_CACHE=gpurun_out/tune_cache_${WL}_fp32.json python3 -m pytest tests/test_gpu_model.py -m gpu -x -q \
+      -k "test_full_batch_fp32_forward_rows_vs_reference and $WL" > gpurun_out/tune_fp32_$WL.log 2>&1 || echo "tune fp32 $WL failed"
+  echo "tuned ${WL}_fp32"
+done
